@@ -1,0 +1,99 @@
+"""ctypes binding of include/bsarec_hip.h.  Fails loudly: there is no CPU or PyTorch fallback."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbsarec_hip.so")
+MAX_LAYERS = 16
+ABI_VERSION = 1
+
+(BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX) = range(9)
+K_NONE, K_FFN1, K_FFN2, K_QKV, K_LOGITS, K_DU, K_DW1 = range(7)
+
+LAYER_FIELDS = ["sqrt_beta", "filter_ln_w", "filter_ln_b", "query_w", "query_b", "key_w", "key_b", "value_w", "value_b",
+                "dense_w", "dense_b", "attn_ln_w", "attn_ln_b", "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b", "ffn_ln_w",
+                "ffn_ln_b"]
+# C field name -> state_dict suffix under item_encoder.blocks.{l}.
+LAYER_KEYS = {
+    "sqrt_beta": "layer.filter_layer.sqrt_beta",
+    "filter_ln_w": "layer.filter_layer.LayerNorm.weight", "filter_ln_b": "layer.filter_layer.LayerNorm.bias",
+    "query_w": "layer.attention_layer.query.weight", "query_b": "layer.attention_layer.query.bias",
+    "key_w": "layer.attention_layer.key.weight", "key_b": "layer.attention_layer.key.bias",
+    "value_w": "layer.attention_layer.value.weight", "value_b": "layer.attention_layer.value.bias",
+    "dense_w": "layer.attention_layer.dense.weight", "dense_b": "layer.attention_layer.dense.bias",
+    "attn_ln_w": "layer.attention_layer.LayerNorm.weight", "attn_ln_b": "layer.attention_layer.LayerNorm.bias",
+    "ffn1_w": "feed_forward.dense_1.weight", "ffn1_b": "feed_forward.dense_1.bias",
+    "ffn2_w": "feed_forward.dense_2.weight", "ffn2_b": "feed_forward.dense_2.bias",
+    "ffn_ln_w": "feed_forward.LayerNorm.weight", "ffn_ln_b": "feed_forward.LayerNorm.bias",
+}
+TOP_KEYS = {"item_emb": "item_embeddings.weight", "pos_emb": "position_embeddings.weight",
+            "ln_w": "LayerNorm.weight", "ln_b": "LayerNorm.bias"}
+
+
+class Config(C.Structure):
+    _fields_ = [("batch", C.c_int), ("seq_len", C.c_int), ("hidden", C.c_int), ("heads", C.c_int), ("layers", C.c_int),
+                ("item_size", C.c_int), ("cutoff_bins", C.c_int), ("alpha", C.c_float), ("ln_eps", C.c_float),
+                ("p_hidden", C.c_float), ("p_attn", C.c_float)]
+
+
+class Layer(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in LAYER_FIELDS]
+
+
+class Tensors(C.Structure):
+    _fields_ = [("item_emb", C.c_void_p), ("pos_emb", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
+                ("layer", Layer * MAX_LAYERS)]
+
+
+EXPORTS = {
+    "bsarec_abi_version": (C.c_int, []),
+    "bsarec_workspace_bytes": (C.c_size_t, [C.POINTER(Config)]),
+    "bsarec_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config), C.POINTER(Tensors), C.POINTER(Tensors),
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_plan_destroy": (None, [C.c_void_p]),
+    "bsarec_buffer_offset": (C.c_long, [C.c_void_p, C.c_int, C.c_int]),
+    "bsarec_step_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsarec_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "bsarec_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_logits": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsarec_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsarec_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_float,
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "bsarec_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "bsarec_freq_layer_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_int,
+                                                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_freq_layer_bwd_scratch_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),
+    "bsarec_freq_layer_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_int] +
+                              [C.c_void_p] * 6),
+    "bsarec_profile_select": (C.c_int, [C.c_int]),
+    "bsarec_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library and bind every symbol of the header.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m bsarec_amd.build` (hipcc, gfx950). "
+            "bsarec_amd has no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)       # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bsarec_abi_version() != ABI_VERSION:
+        raise RuntimeError("libbsarec_hip.so ABI version mismatch: rebuild with `python -m bsarec_amd.build --force`")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = "invalid argument / unsupported shape" if rc < 0 else "hipError_t"
+        raise RuntimeError(f"{what} failed: {kind} {rc}")

@@ -1,0 +1,43 @@
+"""Build the gfx950 shared library in-tree with hipcc (cross-compiles without a GPU).
+
+    python -m bsarec_amd.build          # -> bsarec_amd/libbsarec_hip.so
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "bsarec_hip.hip")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("bsarec_hip.hip", "common.h", "gemm.h", "epilogues.h", "kernels.h")]
+DEPS.append(os.path.join(os.path.dirname(HERE), "include", "bsarec_hip.h"))
+OUT = os.path.join(HERE, "libbsarec_hip.so")
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def is_stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=True):
+    if not force and not is_stale():
+        return OUT
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+           SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,754 @@
+// MI355X (gfx950) BSARec training hot path: launch plan + C ABI.  See include/bsarec_hip.h.
+#include "../../include/bsarec_hip.h"
+#include "epilogues.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define RET(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline long rup(long a, long b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------
+// in-process kernel timing (bench.py roofline): hipEvent pairs around one kernel class
+// ---------------------------------------------------------------------------------------------
+static int g_prof_class = BSAREC_K_NONE;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static size_t g_prof_used = 0;
+
+struct ProfScope {
+    hipStream_t s; bool on; hipEvent_t stop;
+    ProfScope(int kclass, hipStream_t st) : s(st), on(kclass != BSAREC_K_NONE && kclass == g_prof_class) {
+        if (!on) return;
+        if (g_prof_used == g_prof_events.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            g_prof_events.push_back({a, b});
+        }
+        (void)hipEventRecord(g_prof_events[g_prof_used].first, s);
+        stop = g_prof_events[g_prof_used].second;
+        ++g_prof_used;
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(stop, s); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// GEMM launcher
+// ---------------------------------------------------------------------------------------------
+static GemmP gemm_defaults(int M, int N, int K) {
+    GemmP P;
+    memset(&P, 0, sizeof(P));
+    P.M = M; P.N = N; P.K = K; P.Nb = N; P.Kv = K;
+    P.nseg = 1; P.nprob = 1; P.nsplit = 1; P.kchunk = K; P.nh = 1;
+    return P;
+}
+
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AXF, int BXF, bool BG, class Epi>
+static int launch_gemm(const GemmP& P, const XformP& X, const Epi& epi, float* bgrad, int nbatch, hipStream_t s,
+                       int kclass = BSAREC_K_NONE) {
+    auto kern = gemm_kernel<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, Epi>;
+    constexpr size_t smem = GemmSmem<BM, BN, AKM, BKM>::BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (smem > 48 * 1024)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    if (P.M <= 0 || P.N <= 0) return 0;
+    dim3 grid(cdiv(P.M, BM), cdiv(P.N, BN), nbatch * P.nprob * P.nsplit);
+    ProfScope prof(kclass, s);
+    hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), smem, s, P, X, epi, bgrad);
+    return (int)hipGetLastError();
+}
+
+static XformP no_xform() { XformP X; memset(&X, 0, sizeof(X)); return X; }
+
+template <bool BIAS, bool ADD, bool GGRAD>
+static EpiLinear<BIAS, ADD, GGRAD> epi_linear(float* C, long ldc) {
+    EpiLinear<BIAS, ADD, GGRAD> e;
+    memset(&e, 0, sizeof(e));
+    e.C[0] = C; e.ldc = ldc;
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------
+struct LayerBufs {
+    float *dsp, *xhat_f, *rstd_f, *q, *k, *v, *probs, *ctx, *xhat_a, *rstd_a, *hmix, *u, *xhat_ff, *rstd_ff;
+};
+
+struct bsarec_plan {
+    bsarec_config_t cfg;
+    bsarec_tensors_t P, G;
+    char* ws; size_t ws_bytes;
+    uint64_t* state;
+    const float* twiddle;
+    int T, Lp, Vp, dh, nblk, nsplit, kchunk, vsplit, vchunk;
+    bool train;        // mode of the last forward
+    // activations kept for backward
+    int* ids32;
+    float* X[BSAREC_MAX_LAYERS + 1];
+    float *xhat0, *rstd0;
+    LayerBufs lb[BSAREC_MAX_LAYERS];
+    float *logits, *dlogits, *loss_rows, *loss;
+    // backward scratch (shared by all layers)
+    float *dXa, *dXb, *dz, *dT, *dU, *dH, *dXacc, *dO, *dF, *dC, *dS, *dq, *dk, *dv, *dXtmp, *dlast_slab;
+    float *slab_w, *slab_b, *part_ln, *part_beta;
+    ReduceJob* jobs; int jobs_per_layer;
+};
+
+struct Carver {
+    char* base; size_t off;
+    explicit Carver(char* b) : base(b), off(0) {}
+    template <class T> T* take(size_t n) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += rup((long)(n * sizeof(T)), 256);
+        return p;
+    }
+};
+
+static int check_cfg(const bsarec_config_t& c) {
+    if (c.batch < 1 || c.seq_len < 1 || c.seq_len > 256) return -1;
+    if (c.hidden < 4 || c.hidden > 256 || c.hidden % 4) return -2;
+    if (c.heads < 1 || c.hidden % c.heads || (c.hidden / c.heads) % 4) return -3;
+    if (c.layers < 1 || c.layers > BSAREC_MAX_LAYERS) return -4;
+    if (c.item_size < 2) return -5;
+    if (c.cutoff_bins < 1 || c.cutoff_bins > c.seq_len / 2 + 1) return -6;
+    if ((long)c.cutoff_bins * c.hidden > 8192) return -7;      // spectrum must fit the LDS carve
+    if (c.p_hidden < 0.f || c.p_hidden >= 1.f || c.p_attn < 0.f || c.p_attn >= 1.f) return -8;
+    return 0;
+}
+
+static void derive(bsarec_plan& p) {
+    const bsarec_config_t& c = p.cfg;
+    p.T = c.batch * c.seq_len;
+    p.Lp = (int)rup(c.seq_len, 4);
+    p.Vp = (int)rup(c.item_size, 4);
+    p.dh = c.hidden / c.heads;
+    p.nblk = cdiv(p.T, 64);
+    // split-K over tokens for the weight-gradient products: ~96 slices, 32-aligned chunks
+    long ch = rup(cdiv(p.T, 96), GEMM_BK);
+    if (ch < 64) ch = 64;
+    if (ch > 2048) ch = 2048;
+    p.kchunk = (int)ch;
+    p.nsplit = cdiv(p.T, p.kchunk);
+    // split-K over the catalogue for d(h_last) = dlogits . E
+    long vc = rup(cdiv(p.Vp, 128), GEMM_BK);
+    if (vc < 64) vc = 64;
+    p.vchunk = (int)vc;
+    p.vsplit = cdiv(p.Vp, p.vchunk);
+}
+
+static void carve(bsarec_plan& p, char* base, size_t* total) {
+    const bsarec_config_t& c = p.cfg;
+    const long T = p.T, d = c.hidden, B = c.batch, L = c.seq_len, h = c.heads, N = c.layers;
+    const long Td = T * d;
+    Carver cv(base);
+    p.jobs = cv.take<ReduceJob>((size_t)(N * 19 + 2));
+    p.ids32 = cv.take<int>(T);
+    for (int l = 0; l <= N; ++l) p.X[l] = cv.take<float>(Td);
+    p.xhat0 = cv.take<float>(Td); p.rstd0 = cv.take<float>(T);
+    for (int l = 0; l < N; ++l) {
+        LayerBufs& b = p.lb[l];
+        b.dsp = cv.take<float>(Td); b.xhat_f = cv.take<float>(Td); b.rstd_f = cv.take<float>(T);
+        b.q = cv.take<float>(Td); b.k = cv.take<float>(Td); b.v = cv.take<float>(Td);
+        b.probs = cv.take<float>(B * h * L * p.Lp); b.ctx = cv.take<float>(Td);
+        b.xhat_a = cv.take<float>(Td); b.rstd_a = cv.take<float>(T); b.hmix = cv.take<float>(Td);
+        b.u = cv.take<float>(4 * Td); b.xhat_ff = cv.take<float>(Td); b.rstd_ff = cv.take<float>(T);
+    }
+    p.logits = cv.take<float>(B * p.Vp); p.dlogits = cv.take<float>(B * p.Vp);
+    p.loss_rows = cv.take<float>(B); p.loss = cv.take<float>(4);
+    p.dXa = cv.take<float>(Td); p.dXb = cv.take<float>(Td); p.dz = cv.take<float>(Td); p.dT = cv.take<float>(Td);
+    p.dU = cv.take<float>(4 * Td); p.dH = cv.take<float>(Td); p.dXacc = cv.take<float>(Td); p.dO = cv.take<float>(Td);
+    p.dF = cv.take<float>(Td); p.dC = cv.take<float>(Td); p.dS = cv.take<float>(B * h * L * p.Lp);
+    p.dq = cv.take<float>(Td); p.dk = cv.take<float>(Td); p.dv = cv.take<float>(Td); p.dXtmp = cv.take<float>(Td);
+    p.dlast_slab = cv.take<float>((long)p.vsplit * B * d);
+    p.slab_w = cv.take<float>((long)p.nsplit * 12 * d * d);      // wq wk wv wo (d*d each) + w1 w2 (4 d*d each)
+    p.slab_b = cv.take<float>((long)p.nsplit * 9 * d);           // bq bk bv bo (d) + b1 (4d) + b2 (d)
+    p.part_ln = cv.take<float>((long)p.nblk * 6 * d);            // gamma/beta partials of the 3 LayerNorms
+    p.part_beta = cv.take<float>(B * d);
+    *total = cv.off;
+}
+
+extern "C" int bsarec_abi_version(void) { return BSAREC_ABI_VERSION; }
+
+extern "C" size_t bsarec_workspace_bytes(const bsarec_config_t* cfg) {
+    if (!cfg || check_cfg(*cfg) != 0) return 0;
+    bsarec_plan p;
+    p.cfg = *cfg;
+    derive(p);
+    size_t total = 0;
+    carve(p, nullptr, &total);
+    return total;
+}
+
+// slab sub-offsets (floats) inside slab_w / slab_b, per split-K slice
+struct SlabMap { long wq, wk, wv, wo, w1, w2, wtot, bq, bk, bv, bo, b1, b2, btot; };
+static SlabMap slab_map(long d) {
+    SlabMap m;
+    m.wq = 0; m.wk = d * d; m.wv = 2 * d * d; m.wo = 3 * d * d; m.w1 = 4 * d * d; m.w2 = 8 * d * d; m.wtot = 12 * d * d;
+    m.bq = 0; m.bk = d; m.bv = 2 * d; m.bo = 3 * d; m.b1 = 4 * d; m.b2 = 8 * d; m.btot = 9 * d;
+    return m;
+}
+
+// Split-K slabs are stored [tensor][split][elements] so that one reduce job reads a fixed stride.
+static float* slab_w_ptr(const bsarec_plan& p, long tensor_off) { return p.slab_w + tensor_off * p.nsplit; }
+static float* slab_b_ptr(const bsarec_plan& p, long tensor_off) { return p.slab_b + tensor_off * p.nsplit; }
+
+extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cfg, const bsarec_tensors_t* params,
+                                  const bsarec_tensors_t* grads, void* workspace, size_t workspace_bytes,
+                                  void* state, const float* twiddle, void* stream) {
+    if (!out || !cfg || !params || !workspace || !state || !twiddle) return -10;
+    RET(check_cfg(*cfg));
+    if (((uintptr_t)workspace & 255) != 0) return -11;
+    bsarec_plan* p = new bsarec_plan();
+    p->cfg = *cfg;
+    p->P = *params;
+    if (grads) p->G = *grads; else memset(&p->G, 0, sizeof(p->G));
+    p->ws = (char*)workspace; p->ws_bytes = workspace_bytes;
+    p->state = (uint64_t*)state; p->twiddle = twiddle; p->train = false;
+    derive(*p);
+    size_t total = 0;
+    carve(*p, p->ws, &total);
+    if (total > workspace_bytes) { delete p; return -12; }
+
+    // reduction job table: per layer 19 jobs (state_dict order), then the 2 embedding LayerNorm jobs
+    const long d = cfg->hidden;
+    const SlabMap sm = slab_map(d);
+    std::vector<ReduceJob> jobs;
+    auto add = [&](const float* src, float* dst, int nsplit, long len) {
+        ReduceJob j; j.src = src; j.dst = dst; j.nsplit = nsplit; j.len = (int)len; j.stride = len; j.scale = 1.f; j.pad = 0;
+        jobs.push_back(j);
+    };
+    const int ns = p->nsplit, nb = p->nblk;
+    for (int l = 0; l < cfg->layers; ++l) {
+        const bsarec_layer_t& g = p->G.layer[l];
+        add(p->part_beta, g.sqrt_beta, cfg->batch, d);
+        add(p->part_ln + 4L * nb * d, g.filter_ln_w, nb, d);
+        add(p->part_ln + 5L * nb * d, g.filter_ln_b, nb, d);
+        add(slab_w_ptr(*p, sm.wq), g.query_w, ns, d * d); add(slab_b_ptr(*p, sm.bq), g.query_b, ns, d);
+        add(slab_w_ptr(*p, sm.wk), g.key_w, ns, d * d);   add(slab_b_ptr(*p, sm.bk), g.key_b, ns, d);
+        add(slab_w_ptr(*p, sm.wv), g.value_w, ns, d * d); add(slab_b_ptr(*p, sm.bv), g.value_b, ns, d);
+        add(slab_w_ptr(*p, sm.wo), g.dense_w, ns, d * d); add(slab_b_ptr(*p, sm.bo), g.dense_b, ns, d);
+        add(p->part_ln + 2L * nb * d, g.attn_ln_w, nb, d);
+        add(p->part_ln + 3L * nb * d, g.attn_ln_b, nb, d);
+        add(slab_w_ptr(*p, sm.w1), g.ffn1_w, ns, 4 * d * d); add(slab_b_ptr(*p, sm.b1), g.ffn1_b, ns, 4 * d);
+        add(slab_w_ptr(*p, sm.w2), g.ffn2_w, ns, 4 * d * d); add(slab_b_ptr(*p, sm.b2), g.ffn2_b, ns, d);
+        add(p->part_ln + 0L * nb * d, g.ffn_ln_w, nb, d);
+        add(p->part_ln + 1L * nb * d, g.ffn_ln_b, nb, d);
+    }
+    add(p->part_ln + 0L * nb * d, p->G.ln_w, nb, d);
+    add(p->part_ln + 1L * nb * d, p->G.ln_b, nb, d);
+    p->jobs_per_layer = 19;
+    hipError_t e = hipMemcpyAsync(p->jobs, jobs.data(), jobs.size() * sizeof(ReduceJob), hipMemcpyHostToDevice,
+                                  (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);   // jobs vector is host-temporary
+    if (e != hipSuccess) { delete p; return (int)e; }
+    *out = p;
+    return 0;
+}
+
+extern "C" void bsarec_plan_destroy(bsarec_plan_t* plan) { delete plan; }
+
+extern "C" long bsarec_buffer_offset(const bsarec_plan_t* p, int buffer, int layer) {
+    if (!p) return -1;
+    const int N = p->cfg.layers;
+    const void* ptr = nullptr;
+    switch (buffer) {
+        case BSAREC_BUF_LAYER_OUT: if (layer < 0 || layer > N) return -1; ptr = p->X[layer]; break;
+        case BSAREC_BUF_LOGITS: ptr = p->logits; break;
+        case BSAREC_BUF_LOSS: ptr = p->loss; break;
+        case BSAREC_BUF_LOSS_ROWS: ptr = p->loss_rows; break;
+        case BSAREC_BUF_DSP: if (layer < 0 || layer >= N) return -1; ptr = p->lb[layer].dsp; break;
+        case BSAREC_BUF_HMIX: if (layer < 0 || layer >= N) return -1; ptr = p->lb[layer].hmix; break;
+        case BSAREC_BUF_PROBS: if (layer < 0 || layer >= N) return -1; ptr = p->lb[layer].probs; break;
+        case BSAREC_BUF_CTX: if (layer < 0 || layer >= N) return -1; ptr = p->lb[layer].ctx; break;
+        case BSAREC_BUF_DLAYER_IN: if (layer < 0 || layer > N) return -1; ptr = (layer & 1) ? p->dXb : p->dXa; break;
+        default: return -1;
+    }
+    return (long)((const char*)ptr - p->ws);
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+static uint32_t drop_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t <= 0) return 0;
+    if (t >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)t;
+}
+static DropP make_drop(const bsarec_plan& p, float prob, int site, bool train) {
+    DropP d;
+    d.thresh = train ? drop_thresh(prob) : 0;
+    d.scale = (train && prob > 0.f) ? (float)(1.0 / (1.0 - (double)prob)) : 1.0f;
+    d.rng = p.state; d.site = (uint32_t)site;
+    return d;
+}
+static int lpr_for(int d) { return d <= 64 ? 16 : (d <= 128 ? 32 : 64); }
+
+#define DISPATCH_LPR(d, ...) \
+    do { switch (lpr_for(d)) { case 16: { constexpr int LPR = 16; __VA_ARGS__; } break; \
+                               case 32: { constexpr int LPR = 32; __VA_ARGS__; } break; \
+                               default: { constexpr int LPR = 64; __VA_ARGS__; } break; } } while (0)
+
+// tiles whose epilogue needs a whole row of width n (<= 256): pick BN
+#define DISPATCH_BN(n, ...) \
+    do { if ((n) <= 64) { constexpr int BN = 64; __VA_ARGS__; } \
+         else if ((n) <= 128) { constexpr int BN = 128; __VA_ARGS__; } \
+         else { constexpr int BN = 256; __VA_ARGS__; } } while (0)
+
+static size_t freq_smem(int L, int d, int cb, int nsrc) {
+    return (size_t)(rup(2 * L, 4) + (long)nsrc * cb * 2 * d + (long)nsrc * 8192) * 4;
+}
+
+template <int LPR>
+static int launch_freq_fwd(const float* X, const float* sb, const float* g, const float* be, float eps, DropP drop,
+                           const float* tw, int B, int L, int d, int cb, float* dsp, float* xhat, float* rstd, hipStream_t s) {
+    auto kern = freq_fwd_kernel<LPR>;
+    const size_t smem = freq_smem(L, d, cb, 1);
+    static size_t attr = 0;
+    if (smem > 48 * 1024 && smem > attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = smem;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, sb, g, be, eps, drop, tw, L, d, cb, dsp, xhat, rstd);
+    return (int)hipGetLastError();
+}
+
+template <int LPR>
+static int launch_freq_bwd(const float* X, const float* dF, const float* dXin, const float* sb, const float* tw, int B, int L,
+                           int d, int cb, float* dX, float* pbeta, hipStream_t s) {
+    auto kern = freq_bwd_kernel<LPR>;
+    const size_t smem = freq_smem(L, d, cb, 2);
+    static size_t attr = 0;
+    if (smem > 48 * 1024 && smem > attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = smem;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, dF, dXin, sb, tw, L, d, cb, dX, pbeta);
+    return (int)hipGetLastError();
+}
+
+static int launch_reduce(const ReduceJob* jobs, int njobs, long maxlen, hipStream_t s) {
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(cdiv(maxlen, ROW_THREADS), njobs), dim3(ROW_THREADS), 0, s, jobs);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_step_begin(bsarec_plan_t* p, void* stream) {
+    if (!p) return -10;
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+extern "C" int bsarec_forward(bsarec_plan_t* p, const int64_t* ids, int train, void* stream) {
+    if (!p || !ids) return -10;
+    hipStream_t s = (hipStream_t)stream;
+    const bsarec_config_t& c = p->cfg;
+    const int T = p->T, d = c.hidden, L = c.seq_len, B = c.batch, h = c.heads, dh = p->dh, Lp = p->Lp;
+    const bool tr = train != 0;
+    p->train = tr;
+    const XformP nox = no_xform();
+
+    DISPATCH_LPR(d, {
+        constexpr int RPB = ROW_THREADS / LPR;
+        hipLaunchKernelGGL(embed_fwd_kernel<LPR>, dim3(cdiv(T, RPB)), dim3(ROW_THREADS), 0, s, ids, p->P.item_emb,
+                           p->P.pos_emb, p->P.ln_w, p->P.ln_b, c.ln_eps, make_drop(*p, c.p_hidden, 0, tr), T, L, d,
+                           c.item_size, p->X[0], p->xhat0, p->rstd0, p->ids32);
+        HIPCHK(hipGetLastError());
+    });
+
+    for (int l = 0; l < c.layers; ++l) {
+        const bsarec_layer_t& w = p->P.layer[l];
+        LayerBufs& b = p->lb[l];
+        const float* X = p->X[l];
+        // K2 FrequencyLayer
+        DISPATCH_LPR(d, RET(launch_freq_fwd<LPR>(X, w.sqrt_beta, w.filter_ln_w, w.filter_ln_b, c.ln_eps,
+                                                 make_drop(*p, c.p_hidden, 1 + 4 * l, tr), p->twiddle, B, L, d,
+                                                 c.cutoff_bins, b.dsp, b.xhat_f, b.rstd_f, s)));
+        // K3 Q, K, V projections (one launch, 3 problems)
+        {
+            GemmP g = gemm_defaults(T, d, d);
+            g.nprob = 3; g.lda = d; g.ldb = d;
+            g.A[0] = g.A[1] = g.A[2] = X;
+            g.B[0] = w.query_w; g.B[1] = w.key_w; g.B[2] = w.value_w;
+            auto e = epi_linear<true, false, false>(b.q, d);
+            e.C[1] = b.k; e.C[2] = b.v;
+            e.bias[0] = w.query_b; e.bias[1] = w.key_b; e.bias[2] = w.value_b;
+            RET((launch_gemm<64, 64, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s, BSAREC_K_QKV)));
+        }
+        // K4a scores + mask + softmax -> probs
+        {
+            GemmP g = gemm_defaults(L, Lp, dh);
+            g.Nb = L; g.lda = d; g.ldb = d; g.nh = h;
+            g.A[0] = b.q; g.B[0] = b.k;
+            g.a_sb = (long)L * d; g.a_sh = dh; g.b_sb = (long)L * d; g.b_sh = dh;
+            EpiSoftmax e; e.ids = p->ids32; e.L = L; e.Lp = Lp; e.sqrt_dh = sqrtf((float)dh); e.P = b.probs;
+            DISPATCH_BN(Lp, RET((launch_gemm<64, BN, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, B * h, s))));
+        }
+        // K4b context = Drop(probs) . V
+        {
+            GemmP g = gemm_defaults(L, dh, Lp);
+            g.Kv = L; g.lda = Lp; g.ldb = d; g.nh = h;
+            g.A[0] = b.probs; g.B[0] = b.v;
+            g.a_sb = (long)h * L * Lp; g.a_sh = (long)L * Lp; g.b_sb = (long)L * d; g.b_sh = dh;
+            XformP xf = nox; xf.drop = make_drop(*p, c.p_attn, 2 + 4 * l, tr); xf.L = L; xf.Lp = Lp;
+            auto e = epi_linear<false, false, false>(b.ctx, d);
+            e.c_sb = (long)L * d; e.c_sh = dh;
+            RET((launch_gemm<64, 64, 2, 2, false, true, XF_DROP, XF_NONE, false>(g, xf, e, nullptr, B * h, s)));
+        }
+        // K5 dense + dropout + residual + LayerNorm + alpha mix
+        {
+            GemmP g = gemm_defaults(T, d, d);
+            g.lda = d; g.ldb = d; g.A[0] = b.ctx; g.B[0] = w.dense_w;
+            EpiLN<true> e;
+            e.bias = w.dense_b; e.R = X; e.drop = make_drop(*p, c.p_hidden, 3 + 4 * l, tr);
+            e.gamma = w.attn_ln_w; e.beta = w.attn_ln_b; e.eps = c.ln_eps;
+            e.Y = b.hmix; e.xhat = b.xhat_a; e.rstd = b.rstd_a;
+            e.dsp = b.dsp; e.alpha = c.alpha; e.oma = (float)(1.0 - (double)c.alpha);
+            DISPATCH_BN(d, RET((launch_gemm<64, BN, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s))));
+        }
+        // K6a dense_1
+        {
+            GemmP g = gemm_defaults(T, 4 * d, d);
+            g.lda = d; g.ldb = d; g.A[0] = b.hmix; g.B[0] = w.ffn1_w;
+            auto e = epi_linear<true, false, false>(b.u, 4 * d);
+            e.bias[0] = w.ffn1_b;
+            RET((launch_gemm<64, 64, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s, BSAREC_K_FFN1)));
+        }
+        // K6b gelu + dense_2 + dropout + residual + LayerNorm
+        {
+            GemmP g = gemm_defaults(T, d, 4 * d);
+            g.lda = 4 * d; g.ldb = 4 * d; g.A[0] = b.u; g.B[0] = w.ffn2_w;
+            EpiLN<false> e;
+            e.bias = w.ffn2_b; e.R = b.hmix; e.drop = make_drop(*p, c.p_hidden, 4 + 4 * l, tr);
+            e.gamma = w.ffn_ln_w; e.beta = w.ffn_ln_b; e.eps = c.ln_eps;
+            e.Y = p->X[l + 1]; e.xhat = b.xhat_ff; e.rstd = b.rstd_ff;
+            e.dsp = nullptr; e.alpha = 0.f; e.oma = 1.f;
+            DISPATCH_BN(d, RET((launch_gemm<64, BN, 2, 2, false, false, XF_GELU, XF_NONE, false>(g, nox, e, nullptr, 1, s, BSAREC_K_FFN2))));
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// logits / loss
+// ---------------------------------------------------------------------------------------------
+extern "C" int bsarec_logits(bsarec_plan_t* p, void* stream) {
+    if (!p) return -10;
+    hipStream_t s = (hipStream_t)stream;
+    const bsarec_config_t& c = p->cfg;
+    const int d = c.hidden, L = c.seq_len;
+    GemmP g = gemm_defaults(c.batch, p->Vp, d);
+    g.Nb = c.item_size; g.lda = (long)L * d; g.ldb = d;
+    g.A[0] = p->X[c.layers] + (long)(L - 1) * d; g.B[0] = p->P.item_emb;
+    auto e = epi_linear<false, false, false>(p->logits, p->Vp);
+    return launch_gemm<64, 64, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, no_xform(), e, nullptr, 1, s, BSAREC_K_LOGITS);
+}
+
+extern "C" int bsarec_loss(bsarec_plan_t* p, const int64_t* answers, void* stream) {
+    if (!p || !answers) return -10;
+    hipStream_t s = (hipStream_t)stream;
+    RET(bsarec_logits(p, stream));
+    const bsarec_config_t& c = p->cfg;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, c.item_size, p->Vp,
+                       1.0f / (float)c.batch, p->dlogits, p->loss_rows);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->loss_rows, c.batch, p->loss);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
+    if (!p) return -10;
+    if (!p->G.item_emb) return -13;
+    hipStream_t s = (hipStream_t)stream;
+    const bsarec_config_t& c = p->cfg;
+    const int T = p->T, d = c.hidden, L = c.seq_len, B = c.batch, h = c.heads, dh = p->dh, Lp = p->Lp, N = c.layers;
+    const bool tr = p->train;
+    const XformP nox = no_xform();
+    const SlabMap sm = slab_map(d);
+    const int ns = p->nsplit, nb = p->nblk;
+    const float* hlast = p->X[N] + (long)(L - 1) * d;
+
+    // dE (dense, logits path) = dlogits^T . h_last       [V, d], overwrites the gradient buffer
+    {
+        GemmP g = gemm_defaults(c.item_size, d, B);
+        g.lda = p->Vp; g.ldb = (long)L * d; g.A[0] = p->dlogits; g.B[0] = hlast;
+        auto e = epi_linear<false, false, false>(p->G.item_emb, d);
+        RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
+    }
+    // d(h_last) = dlogits . E, split-K over the catalogue, then scatter into the (otherwise zero) dX^N
+    {
+        GemmP g = gemm_defaults(B, d, p->Vp);
+        g.Kv = c.item_size; g.lda = p->Vp; g.ldb = d; g.A[0] = p->dlogits; g.B[0] = p->P.item_emb;
+        g.nsplit = p->vsplit; g.kchunk = p->vchunk;
+        auto e = epi_linear<false, false, false>(p->dlast_slab, d);
+        e.c_split = (long)B * d;
+        RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
+    }
+    float* dY = (N & 1) ? p->dXb : p->dXa;       // gradient w.r.t. X[l+1]; ping-pong so that dX[0] lands in dXa
+    hipLaunchKernelGGL(dlast_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, p->dlast_slab,
+                       p->vsplit, (long)B * d, T, L, d, dY);
+    HIPCHK(hipGetLastError());
+
+    for (int l = N - 1; l >= 0; --l) {
+        const bsarec_layer_t& w = p->P.layer[l];
+        LayerBufs& b = p->lb[l];
+        const float* X = p->X[l];
+        float* dXout = (dY == p->dXa) ? p->dXb : p->dXa;
+        // ---- FeedForward backward
+        {
+            LnBranch a; memset(&a, 0, sizeof(a));
+            a.xhat = b.xhat_ff; a.rstd = b.rstd_ff; a.gamma = w.ffn_ln_w; a.in_scale = 1.f;
+            a.drop = make_drop(*p, c.p_hidden, 4 + 4 * l, tr); a.dT = p->dT;
+            a.pgamma = p->part_ln + 0L * nb * d; a.pbeta = p->part_ln + 1L * nb * d;
+            DISPATCH_LPR(d, hipLaunchKernelGGL((ln_bwd_kernel<LPR, 0>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, 64));
+            HIPCHK(hipGetLastError());
+        }
+        {   // dU = (dT2 . W2) * gelu'(U)
+            GemmP g = gemm_defaults(T, 4 * d, d);
+            g.lda = d; g.ldb = 4 * d; g.A[0] = p->dT; g.B[0] = w.ffn2_w;
+            auto e = epi_linear<false, false, true>(p->dU, 4 * d);
+            e.U = b.u; e.ldu = 4 * d;
+            RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s, BSAREC_K_DU)));
+        }
+        {   // dW2 = dT2^T . gelu(U), db2
+            GemmP g = gemm_defaults(d, 4 * d, T);
+            g.lda = d; g.ldb = 4 * d; g.A[0] = p->dT; g.B[0] = b.u; g.nsplit = ns; g.kchunk = p->kchunk;
+            auto e = epi_linear<false, false, false>(slab_w_ptr(*p, sm.w2), 4 * d);
+            e.c_split = 4L * d * d;
+            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_GELU, true>(g, nox, e, slab_b_ptr(*p, sm.b2), 1, s)));
+        }
+        {   // dH = dU . W1 + dz
+            GemmP g = gemm_defaults(T, d, 4 * d);
+            g.lda = 4 * d; g.ldb = d; g.A[0] = p->dU; g.B[0] = w.ffn1_w;
+            auto e = epi_linear<false, true, false>(p->dH, d);
+            e.R = p->dz; e.ldr = d;
+            RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
+        }
+        {   // dW1 = dU^T . Hmix, db1
+            GemmP g = gemm_defaults(4 * d, d, T);
+            g.lda = 4 * d; g.ldb = d; g.A[0] = p->dU; g.B[0] = b.hmix; g.nsplit = ns; g.kchunk = p->kchunk;
+            auto e = epi_linear<false, false, false>(slab_w_ptr(*p, sm.w1), d);
+            e.c_split = 4L * d * d;
+            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(g, nox, e, slab_b_ptr(*p, sm.b1), 1, s, BSAREC_K_DW1)));
+        }
+        // ---- mix + the two LayerNorms (attention branch scaled by 1-alpha, filter branch by alpha)
+        {
+            LnBranch a; memset(&a, 0, sizeof(a));
+            a.xhat = b.xhat_a; a.rstd = b.rstd_a; a.gamma = w.attn_ln_w; a.in_scale = (float)(1.0 - (double)c.alpha);
+            a.drop = make_drop(*p, c.p_hidden, 3 + 4 * l, tr); a.dT = p->dO;
+            a.pgamma = p->part_ln + 2L * nb * d; a.pbeta = p->part_ln + 3L * nb * d;
+            LnBranch f; memset(&f, 0, sizeof(f));
+            f.xhat = b.xhat_f; f.rstd = b.rstd_f; f.gamma = w.filter_ln_w; f.in_scale = c.alpha;
+            f.drop = make_drop(*p, c.p_hidden, 1 + 4 * l, tr); f.dT = p->dF;
+            f.pgamma = p->part_ln + 4L * nb * d; f.pbeta = p->part_ln + 5L * nb * d;
+            DISPATCH_LPR(d, hipLaunchKernelGGL((ln_bwd_kernel<LPR, 1>), dim3(nb), dim3(ROW_THREADS), 0, s, p->dH, a, f, p->dXacc, T, d, 64));
+            HIPCHK(hipGetLastError());
+        }
+        // ---- attention backward
+        {   // dC = dO . Wo
+            GemmP g = gemm_defaults(T, d, d);
+            g.lda = d; g.ldb = d; g.A[0] = p->dO; g.B[0] = w.dense_w;
+            auto e = epi_linear<false, false, false>(p->dC, d);
+            RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
+        }
+        {   // dWo = dO^T . ctx, dbo
+            GemmP g = gemm_defaults(d, d, T);
+            g.lda = d; g.ldb = d; g.A[0] = p->dO; g.B[0] = b.ctx; g.nsplit = ns; g.kchunk = p->kchunk;
+            auto e = epi_linear<false, false, false>(slab_w_ptr(*p, sm.wo), d);
+            e.c_split = (long)d * d;
+            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(g, nox, e, slab_b_ptr(*p, sm.bo), 1, s)));
+        }
+        XformP xfa = nox; xfa.drop = make_drop(*p, c.p_attn, 2 + 4 * l, tr); xfa.L = L; xfa.Lp = Lp;
+        {   // dS = P * (dA - rowsum(dA P)) / sqrt(dh),  dA = (dC . V^T) * keep/(1-p)
+            GemmP g = gemm_defaults(L, Lp, dh);
+            g.Nb = L; g.lda = d; g.ldb = d; g.nh = h; g.A[0] = p->dC; g.B[0] = b.v;
+            g.a_sb = (long)L * d; g.a_sh = dh; g.b_sb = (long)L * d; g.b_sh = dh;
+            EpiDS e; e.P = b.probs; e.drop = xfa.drop; e.L = L; e.Lp = Lp; e.sqrt_dh = sqrtf((float)dh); e.dS = p->dS;
+            DISPATCH_BN(Lp, RET((launch_gemm<64, BN, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, B * h, s))));
+        }
+        {   // dV = Drop(P)^T . dC
+            GemmP g = gemm_defaults(L, dh, L);
+            g.lda = Lp; g.ldb = d; g.nh = h; g.A[0] = b.probs; g.B[0] = p->dC;
+            g.a_sb = (long)h * L * Lp; g.a_sh = (long)L * Lp; g.b_sb = (long)L * d; g.b_sh = dh;
+            auto e = epi_linear<false, false, false>(p->dv, d);
+            e.c_sb = (long)L * d; e.c_sh = dh;
+            RET((launch_gemm<64, 64, 2, 2, true, true, XF_DROP, XF_NONE, false>(g, xfa, e, nullptr, B * h, s)));
+        }
+        {   // dK = dS^T . Q
+            GemmP g = gemm_defaults(L, dh, L);
+            g.lda = Lp; g.ldb = d; g.nh = h; g.A[0] = p->dS; g.B[0] = b.q;
+            g.a_sb = (long)h * L * Lp; g.a_sh = (long)L * Lp; g.b_sb = (long)L * d; g.b_sh = dh;
+            auto e = epi_linear<false, false, false>(p->dk, d);
+            e.c_sb = (long)L * d; e.c_sh = dh;
+            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, B * h, s)));
+        }
+        {   // dQ = dS . K
+            GemmP g = gemm_defaults(L, dh, Lp);
+            g.Kv = L; g.lda = Lp; g.ldb = d; g.nh = h; g.A[0] = p->dS; g.B[0] = b.k;
+            g.a_sb = (long)h * L * Lp; g.a_sh = (long)L * Lp; g.b_sb = (long)L * d; g.b_sh = dh;
+            auto e = epi_linear<false, false, false>(p->dq, d);
+            e.c_sb = (long)L * d; e.c_sh = dh;
+            RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, B * h, s)));
+        }
+        {   // dXtmp = dQ.Wq + dK.Wk + dV.Wv + (dzA + dzF)
+            GemmP g = gemm_defaults(T, d, d);
+            g.lda = d; g.ldb = d; g.nseg = 3;
+            g.A[0] = p->dq; g.A[1] = p->dk; g.A[2] = p->dv;
+            g.B[0] = w.query_w; g.B[1] = w.key_w; g.B[2] = w.value_w;
+            auto e = epi_linear<false, true, false>(p->dXtmp, d);
+            e.R = p->dXacc; e.ldr = d;
+            RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
+        }
+        {   // dWq, dWk, dWv = {dQ,dK,dV}^T . X  and their bias gradients
+            GemmP g = gemm_defaults(d, d, T);
+            g.lda = d; g.ldb = d; g.nprob = 3; g.nsplit = ns; g.kchunk = p->kchunk;
+            g.A[0] = p->dq; g.A[1] = p->dk; g.A[2] = p->dv;
+            g.B[0] = g.B[1] = g.B[2] = X;
+            auto e = epi_linear<false, false, false>(slab_w_ptr(*p, sm.wq), d);
+            e.C[1] = slab_w_ptr(*p, sm.wk); e.C[2] = slab_w_ptr(*p, sm.wv);
+            e.c_split = (long)d * d;
+            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(g, nox, e, slab_b_ptr(*p, sm.bq), 1, s)));
+        }
+        // ---- FrequencyLayer backward: completes dX of this layer
+        DISPATCH_LPR(d, RET(launch_freq_bwd<LPR>(X, p->dF, p->dXtmp, w.sqrt_beta, p->twiddle, B, L, d, c.cutoff_bins,
+                                                 dXout, p->part_beta, s)));
+        // ---- second-stage reductions of this layer's 19 tensors
+        RET(launch_reduce(p->jobs + (long)l * p->jobs_per_layer, p->jobs_per_layer, 4L * d * d, s));
+        dY = dXout;
+    }
+    // ---- embedding front-end backward
+    {
+        LnBranch a; memset(&a, 0, sizeof(a));
+        a.xhat = p->xhat0; a.rstd = p->rstd0; a.gamma = p->P.ln_w; a.in_scale = 1.f;
+        a.drop = make_drop(*p, c.p_hidden, 0, tr); a.dT = nullptr;
+        a.pgamma = p->part_ln + 0L * nb * d; a.pbeta = p->part_ln + 1L * nb * d;
+        DISPATCH_LPR(d, hipLaunchKernelGGL((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, 64));
+        HIPCHK(hipGetLastError());
+        DISPATCH_LPR(d, {
+            constexpr int RPP = ROW_THREADS / LPR;
+            const int sb = cdiv(T, RPP);
+            hipLaunchKernelGGL(embed_bwd_kernel<LPR>, dim3(sb + L), dim3(ROW_THREADS), 0, s, p->dz, p->ids32, B, L, d,
+                               p->G.item_emb, p->G.pos_emb, sb);
+            HIPCHK(hipGetLastError());
+        });
+        RET(launch_reduce(p->jobs + (long)N * p->jobs_per_layer, 2, d, s));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam / fused step
+// ---------------------------------------------------------------------------------------------
+extern "C" int bsarec_adam_step(float* params, const float* grads, float* m, float* v, long n, void* state, float lr,
+                                float b1, float b2, float eps, float wd, float gscale, void* stream) {
+    if (!params || !grads || !m || !v || !state || n <= 0 || (n & 3)) return -10;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, (uint64_t*)state, (double)lr, (double)b1, (double)b2);
+    HIPCHK(hipGetLastError());
+    const long n4 = n / 4;
+    int blocks = cdiv(n4, ROW_THREADS);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, params, grads, m, v, n4, (const uint64_t*)state,
+                       b1, b2, eps, wd, gscale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int64_t* answers, float* params_flat,
+                                 const float* grads_flat, float* m, float* v, long n, float lr, float b1, float b2,
+                                 float eps, float wd, void* stream) {
+    RET(bsarec_step_begin(p, stream));
+    RET(bsarec_forward(p, ids, 1, stream));
+    RET(bsarec_loss(p, answers, stream));
+    RET(bsarec_backward(p, stream));
+    return bsarec_adam_step(params_flat, grads_flat, m, v, n, p->state, lr, b1, b2, eps, wd, 1.0f, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone FrequencyLayer (per-op parity tests)
+// ---------------------------------------------------------------------------------------------
+static DropP standalone_drop(float p, const void* state, int site) {
+    DropP d;
+    d.thresh = drop_thresh(p);
+    d.scale = p > 0.f ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
+    d.rng = (const uint64_t*)state; d.site = (uint32_t)site;
+    return d;
+}
+
+extern "C" int bsarec_freq_layer_fwd(const float* x, const float* sqrt_beta, const float* ln_w, const float* ln_b,
+                                     const float* twiddle, int B, int L, int d, int cb, float eps, float p_drop,
+                                     const void* state, int site, float* y, float* xhat, float* rstd, void* stream) {
+    if (!x || !y || d % 4 || d > 256 || L > 256 || (long)cb * d > 8192 || (p_drop > 0.f && !state)) return -10;
+    DISPATCH_LPR(d, RET(launch_freq_fwd<LPR>(x, sqrt_beta, ln_w, ln_b, eps, standalone_drop(p_drop, state, site), twiddle,
+                                             B, L, d, cb, y, xhat, rstd, (hipStream_t)stream)));
+    return 0;
+}
+
+extern "C" long bsarec_freq_layer_bwd_scratch_floats(int B, int L, int d) {
+    const long T = (long)B * L;
+    return 3 * T * d + (long)B * d + 2L * cdiv(T, 64) * d + 64;
+}
+
+extern "C" int bsarec_freq_layer_bwd(const float* x, const float* dy, const float* xhat, const float* rstd,
+                                     const float* sqrt_beta, const float* ln_w, const float* twiddle, int B, int L, int d,
+                                     int cb, float p_drop, const void* state, int site, float* scratch, float* dx,
+                                     float* dsqrt_beta, float* dln_w, float* dln_b, void* stream) {
+    if (!x || !dy || !scratch || d % 4 || d > 256 || L > 256 || (long)cb * d > 8192 || (p_drop > 0.f && !state)) return -10;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = B * L, nb = cdiv(T, 64);
+    float* dz = scratch; float* dF = dz + (long)T * d; float* pbeta = dF + (long)T * d;
+    float* pg = pbeta + (long)B * d; float* pb = pg + (long)nb * d;
+    ReduceJob* jobs = reinterpret_cast<ReduceJob*>(pb + (long)nb * d);      // needs 3 jobs: uses the T*d tail
+    jobs = reinterpret_cast<ReduceJob*>(((uintptr_t)jobs + 15) & ~(uintptr_t)15);
+    LnBranch a; memset(&a, 0, sizeof(a));
+    a.xhat = xhat; a.rstd = rstd; a.gamma = ln_w; a.in_scale = 1.f; a.drop = standalone_drop(p_drop, state, site);
+    a.dT = dF; a.pgamma = pg; a.pbeta = pb;
+    DISPATCH_LPR(d, hipLaunchKernelGGL((ln_bwd_kernel<LPR, 0>), dim3(nb), dim3(ROW_THREADS), 0, s, dy, a, a, dz, T, d, 64));
+    HIPCHK(hipGetLastError());
+    // y = LN(Drop(f(x)) + x): the residual contributes dz directly
+    DISPATCH_LPR(d, RET(launch_freq_bwd<LPR>(x, dF, dz, sqrt_beta, twiddle, B, L, d, cb, dx, pbeta, s)));
+    ReduceJob hj[3];
+    hj[0] = ReduceJob{pbeta, dsqrt_beta, B, d, d, 1.f, 0};
+    hj[1] = ReduceJob{pg, dln_w, nb, d, d, 1.f, 0};
+    hj[2] = ReduceJob{pb, dln_b, nb, d, d, 1.f, 0};
+    HIPCHK(hipMemcpyAsync(jobs, hj, sizeof(hj), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return launch_reduce(jobs, 3, d, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling hooks
+// ---------------------------------------------------------------------------------------------
+extern "C" int bsarec_profile_select(int kclass) {
+    g_prof_class = kclass;
+    g_prof_used = 0;
+    return 0;
+}
+
+extern "C" int bsarec_profile_read(double* ms_total, int* launches) {
+    double tot = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        HIPCHK(hipEventSynchronize(g_prof_events[i].second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, g_prof_events[i].first, g_prof_events[i].second));
+        tot += ms;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = (int)g_prof_used;
+    g_prof_used = 0;
+    return 0;
+}

@@ -1,0 +1,82 @@
+// Shared device helpers for the BSARec gfx950 kernels: Philox dropout stream, erf-GELU,
+// wave reductions.  Wave = 64 lanes everywhere (CDNA4); nothing here is portable on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10, counter-based.  Same stream as oracle/bsarec_oracle.py::dropout_keep: element i
+// of dropout site `site` at optimisation step `step` uses counter (i>>2, 0, site, step) keyed by
+// the 64-bit seed and takes output word i&3; an element is kept iff word >= thresh.
+// ---------------------------------------------------------------------------------------------
+struct DropP {
+    uint32_t thresh;            // floor(p * 2^32); 0 disables dropout (eval mode / p = 0)
+    float scale;                // 1 / (1 - p)
+    const uint64_t* rng;        // device: rng[0] = seed, rng[1] = step (read at run time, so a
+                                // captured hipGraph replays with fresh masks)
+    uint32_t site;
+};
+
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// keep-mask x scale for the 4 elements of group `grp` (= element index >> 2)
+__device__ __forceinline__ f32x4 drop_mult4(const DropP& d, uint64_t grp) {
+    f32x4 m = {d.scale, d.scale, d.scale, d.scale};
+    if (d.thresh == 0) return m;
+    const uint64_t seed = d.rng[0];
+    const uint4 w = philox4x32_10((uint32_t)grp, (uint32_t)(grp >> 32), d.site, (uint32_t)d.rng[1],
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+    m.x = w.x >= d.thresh ? d.scale : 0.f;
+    m.y = w.y >= d.thresh ? d.scale : 0.f;
+    m.z = w.z >= d.thresh ? d.scale : 0.f;
+    m.w = w.w >= d.thresh ? d.scale : 0.f;
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// erf-GELU exactly as the reference writes it (src/model/_modules.py:56) and its derivative
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {
+    return x * 0.5f * (1.0f + erff(x / 1.41421356237309515f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x / 1.41421356237309515f));
+    const float pdf = expf(-0.5f * x * x) * 0.39894228040143270f;
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions inside a group of `W` consecutive lanes (W = 16, 32 or 64)
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }

@@ -1,0 +1,253 @@
+// Generic exact-fp32 MFMA GEMM core for gfx950 (v_mfma_f32_32x32x2_f32), used by every
+// contraction on the BSARec path: token-parallel projections (NT), input-gradient products (NN),
+// weight-gradient products (TN, split-K), the batched attention products and the full-catalogue
+// logits.  C[m,n] = sum_k A(m,k) * B(n,k).
+//
+// Layout rules
+//   * an operand whose k index is contiguous in memory ("KC") is staged in LDS row-major
+//     [row][BK+4] and read as one ds_read_b128 per 8-deep k-block: lane (i, half) takes
+//     k = 8*blk + 4*half .. +3, i.e. the k order inside a block is permuted identically for A and
+//     B (a sum over k does not care); the +4 pad makes the 16-lane b128 groups conflict-free.
+//   * an operand whose row index is contiguous ("KM": A^T or B^T products) is staged k-major
+//     [BK][rows] by a straight 16-byte copy and read with four conflict-free ds_read_b32.
+//   * 256 threads = 4 waves arranged WM x WN; each wave owns (BM/WM) x (BN/WN) of the tile as
+//     32x32 MFMA accumulators; global->register->LDS double buffering, one barrier per k-tile.
+//   * the epilogue always goes through an LDS image of the C tile so that every epilogue
+//     (bias, LayerNorm, softmax, gradient fix-ups) reads whole rows and stores 16 B per lane.
+#pragma once
+#include "common.h"
+
+enum { XF_NONE = 0, XF_GELU = 1, XF_DROP = 2 };
+
+#define GEMM_BK 32
+#define GEMM_THREADS 256
+
+struct GemmP {
+    const float* A[3];
+    const float* B[3];
+    int M, N, K;          // N is the padded (multiple of 4) logical width
+    int Nb;               // valid rows of B (<= N); rows beyond are read as zero
+    int Kv;               // valid k extent (<= K) of a k-major operand; K itself may be padded to 4
+    long lda, ldb;        // stride in floats of the non-contiguous dimension of A / B
+    int nseg;             // K segments accumulated into one output (A[s], B[s]), else 1
+    int nprob;            // independent problems selected by blockIdx.z (A[p], B[p]), else 1
+    int nsplit;           // split-K factor, else 1
+    int kchunk;           // K range per split (multiple of GEMM_BK)
+    int nh;               // inner batch count (heads) for batched products, else 1
+    long a_sb, a_sh, b_sb, b_sh;   // batch strides (floats): outer (sequence) and inner (head)
+};
+
+struct XformP {           // operand transform applied while loading
+    DropP drop;           // XF_DROP: attention-probability dropout regenerated on load
+    int L, Lp;            // XF_DROP: element index = ((zb*L + q)*Lp + key)
+};
+
+struct TileCtx {          // what an epilogue needs to know about its tile
+    int m0, n0, M, N;
+    int zb;               // batch index (b*nh + head) or 0
+    int b, hh;            // zb split into (sequence, head)
+    int prob, split;
+};
+
+// ---------------------------------------------------------------------------------------------
+// global -> registers -> LDS tile loader
+// ---------------------------------------------------------------------------------------------
+template <int R, bool KM, int XF>
+struct TileLoader {
+    static constexpr int NV = R * GEMM_BK / 4 / GEMM_THREADS;
+    static_assert(NV >= 1, "tile too small for 256 threads");
+    f32x4 v[NV];
+
+    __device__ __forceinline__ f32x4 xform(f32x4 x, int q, int key0, bool valid, const XformP& X, int zb) const {
+        if (XF == XF_GELU) {
+            x.x = gelu_f(x.x); x.y = gelu_f(x.y); x.z = gelu_f(x.z); x.w = gelu_f(x.w);
+        } else if (XF == XF_DROP) {
+            if (valid) {
+                const uint64_t e = ((uint64_t)zb * X.L + q) * X.Lp + key0;
+                x = x * drop_mult4(X.drop, e >> 2);
+            }
+        }
+        return x;
+    }
+
+    // rows [r0, r0+R) limited by rlim; k range [k0, k0+BK) limited by klim
+    __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int r0, int rlim, int k0, int klim,
+                                         const XformP& X, int zb) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int idx = tid + p * GEMM_THREADS;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (!KM) {
+                const int gr = r0 + (idx >> 3), gk = k0 + ((idx & 7) << 2);
+                const bool ok = gr < rlim && gk < klim;
+                if (ok) x = ld4(base + (long)gr * ld + gk);
+                x = xform(x, gr, gk, ok, X, zb);
+            } else {
+                constexpr int RV = R / 4;
+                const int gk = k0 + idx / RV, gr = r0 + ((idx % RV) << 2);
+                bool ok = false;
+                if (gk < klim) {
+                    const float* src = base + (long)gk * ld + gr;
+                    if (gr + 3 < rlim) { x = ld4(src); ok = true; }
+                    else {
+                        if (gr < rlim) { x.x = src[0]; ok = true; }
+                        if (gr + 1 < rlim) x.y = src[1];
+                        if (gr + 2 < rlim) x.z = src[2];
+                    }
+                }
+                x = xform(x, gk, gr, ok, X, zb);
+            }
+            v[p] = x;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* s) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int idx = tid + p * GEMM_THREADS;
+            if (!KM) st4(s + (idx >> 3) * (GEMM_BK + 4) + ((idx & 7) << 2), v[p]);
+            else { constexpr int RV = R / 4; st4(s + (idx / RV) * R + ((idx % RV) << 2), v[p]); }
+        }
+    }
+};
+
+template <int BM, int BN, bool A_KM, bool B_KM>
+struct GemmSmem {
+    static constexpr int A_TILE = A_KM ? GEMM_BK * BM : BM * (GEMM_BK + 4);
+    static constexpr int B_TILE = B_KM ? GEMM_BK * BN : BN * (GEMM_BK + 4);
+    static constexpr int STAGE = 2 * (A_TILE + B_TILE);
+    static constexpr int LDC = BN + 4;
+    static constexpr int CT = BM * LDC;
+    static constexpr int FLOATS = STAGE > CT ? STAGE : CT;
+    static constexpr size_t BYTES = (size_t)FLOATS * 4;
+};
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, class Epi>
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bgrad /* [nprob][nsplit][M] */) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BK = GEMM_BK;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA");
+    using SM = GemmSmem<BM, BN, A_KM, B_KM>;
+    constexpr int LDAS = A_KM ? BM : BK + 4;
+    constexpr int LDBS = B_KM ? BN : BK + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As0 = smem;
+    float* As1 = smem + SM::A_TILE;
+    float* Bs0 = smem + 2 * SM::A_TILE;
+    float* Bs1 = Bs0 + SM::B_TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wrow = (wave / WN) * WTM, wcol = (wave % WN) * WTN;
+
+    // blockIdx.z -> (batch, problem, split)
+    int z = blockIdx.z;
+    const int split = z % P.nsplit; z /= P.nsplit;
+    const int prob = z % P.nprob;
+    const int zb = z / P.nprob;
+    TileCtx ctx;
+    ctx.m0 = blockIdx.x * BM; ctx.n0 = blockIdx.y * BN; ctx.M = P.M; ctx.N = P.N;
+    ctx.zb = zb; ctx.b = zb / P.nh; ctx.hh = zb % P.nh; ctx.prob = prob; ctx.split = split;
+
+    const long aoff = (long)ctx.b * P.a_sb + (long)ctx.hh * P.a_sh;
+    const long boff = (long)ctx.b * P.b_sb + (long)ctx.hh * P.b_sh;
+    int kbeg = 0, kend = P.K;
+    if (P.nsplit > 1) { kbeg = split * P.kchunk; kend = min(P.K, kbeg + P.kchunk); }
+    const int kvend = min(kend, P.Kv);
+    const int ktiles = (kend - kbeg + BK - 1) / BK;
+    const int nit = ktiles * P.nseg;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum = 0.f;
+
+    TileLoader<BM, A_KM, AXF> la;
+    TileLoader<BN, B_KM, BXF> lb;
+    auto issue = [&](int it) {
+        const int seg = (P.nseg > 1) ? it / ktiles : prob;
+        const int kt = (P.nseg > 1) ? it % ktiles : it;
+        const int k0 = kbeg + kt * BK;
+        la.load(P.A[seg] + aoff, P.lda, ctx.m0, P.M, k0, A_KM ? kvend : kend, X, zb);
+        lb.load(P.B[seg] + boff, P.ldb, ctx.n0, P.Nb, k0, B_KM ? kvend : kend, X, zb);
+    };
+
+    if (nit > 0) {
+        issue(0);
+        la.store(As0);
+        lb.store(Bs0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        const float* as = (it & 1) ? As1 : As0;
+        const float* bs = (it & 1) ? Bs1 : Bs0;
+        if (it + 1 < nit) issue(it + 1);
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wrow + i * 32 + l31;
+                if (!A_KM) af[i] = ld4(as + r * LDAS + kb * 8 + 4 * half);
+                else {
+                    const float* p = as + (kb * 8 + 4 * half) * LDAS + r;
+                    af[i].x = p[0]; af[i].y = p[LDAS]; af[i].z = p[2 * LDAS]; af[i].w = p[3 * LDAS];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wcol + j * 32 + l31;
+                if (!B_KM) bf[j] = ld4(bs + r * LDBS + kb * 8 + 4 * half);
+                else {
+                    const float* p = bs + (kb * 8 + 4 * half) * LDBS + r;
+                    bf[j].x = p[0]; bf[j].y = p[LDBS]; bf[j].z = p[2 * LDBS]; bf[j].w = p[3 * LDBS];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (BGRAD && A_KM && blockIdx.y == 0 && tid < BM) {
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) bsum += as[k * LDAS + tid];
+        }
+        if (it + 1 < nit) {
+            la.store((it & 1) ? As0 : As1);
+            lb.store((it & 1) ? Bs0 : Bs1);
+        }
+        __syncthreads();
+    }
+    if (BGRAD && A_KM && blockIdx.y == 0 && tid < BM && ctx.m0 + tid < P.M)
+        bgrad[((long)prob * P.nsplit + split) * P.M + ctx.m0 + tid] = bsum;
+
+    // accumulators -> LDS image of the C tile (aliases the staging buffers; the loop's last
+    // barrier has already retired every read of them)
+    float* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                Cs[row * SM::LDC + wcol + j * 32 + l31] = acc[i][j][r];
+            }
+    __syncthreads();
+    epi.template run<BM, BN>(Cs, ctx);
+}

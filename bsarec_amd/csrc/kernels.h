@@ -1,0 +1,450 @@
+// Row-parallel (HBM/L2-bound) kernels of the BSARec path: embedding front-end, FrequencyLayer
+// (pruned DFT in LDS), LayerNorm backward, fused cross-entropy, embedding-gradient scatter,
+// deterministic partial reductions and the fused Adam.  Common shape: a row of d floats is held by
+// LPR = {16,32,64} consecutive lanes, 4 consecutive channels per lane (16-byte accesses), so one
+// wave covers 64/LPR rows and row statistics are intra-wave shuffles.
+#pragma once
+#include "common.h"
+
+#define ROW_THREADS 256
+
+// =============================================================================================
+// K1 embedding front-end: X0 = Drop(LN(E[ids] + Pos[t]))      src/model/_abstract_model.py:14-24
+// =============================================================================================
+template <int LPR>
+__global__ void __launch_bounds__(ROW_THREADS)
+embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ E, const float* __restrict__ Pos,
+                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, DropP drop,
+                 int T, int L, int d, int V, float* __restrict__ X0, float* __restrict__ xhat,
+                 float* __restrict__ rstd, int* __restrict__ ids32) {
+    constexpr int RPB = ROW_THREADS / LPR;
+    const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
+    const int tok = blockIdx.x * RPB + lr;
+    const bool ok = tok < T && lc < d;
+    f32x4 v = {0, 0, 0, 0};
+    if (ok) {
+        int id = (int)ids[tok];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);     // defensive clamp: never read outside the table
+        if (lc == 0) ids32[tok] = id;
+        v = ld4(E + (long)id * d + lc) + ld4(Pos + (long)(tok % L) * d + lc);
+    }
+    const float invd = 1.0f / (float)d;
+    const float mean = group_sum<LPR>(v.x + v.y + v.z + v.w) * invd;
+    f32x4 dl = {0, 0, 0, 0};
+    if (ok) dl = v - mean;
+    const float var = group_sum<LPR>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * invd;
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (ok) {
+        const long e = (long)tok * d + lc;
+        const f32x4 xh = dl * rs;
+        st4(xhat + e, xh);
+        st4(X0 + e, (ld4(gamma + lc) * xh + ld4(beta + lc)) * drop_mult4(drop, (uint64_t)e >> 2));
+        if (lc == 0) rstd[tok] = rs;
+    }
+}
+
+// =============================================================================================
+// LayerNorm backward (row op) with the dropout that sits before / after it, plus per-block
+// partial sums of d(gamma), d(beta).   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy*gamma
+// =============================================================================================
+struct LnBranch {
+    const float* xhat; const float* rstd; const float* gamma;
+    float in_scale;            // alpha / (1 - alpha) of the BSARec mix, else 1
+    DropP drop;
+    float* dT;                 // POST-drop output: dz * keep/(1-p)   (gradient of the dropped-out tensor)
+    float* pgamma; float* pbeta;   // [gridDim.x][d] partials
+};
+
+// MODE 0: one branch, dropout AFTER LN in backward order (y = LN(Drop(z) + res)):  dz -> dZ, dT
+// MODE 1: two branches on the same upstream gradient (attention LN and filter LN):
+//         dXacc = dzA + dzF ; dT of each branch
+// MODE 2: embedding: y = Drop(LN(e)):  de = LNbwd(dy * keep/(1-p)) -> dZ
+template <int LPR, int MODE>
+__global__ void __launch_bounds__(ROW_THREADS)
+ln_bwd_kernel(const float* __restrict__ dY, LnBranch a, LnBranch f, float* __restrict__ dZ, int T, int d,
+              int rows_per_block) {
+    constexpr int RPP = ROW_THREADS / LPR;
+    __shared__ float red[4][RPP][LPR * 4];
+    const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
+    const bool colok = lc < d;
+    const float invd = 1.0f / (float)d;
+    f32x4 ga = {0, 0, 0, 0}, gf = ga;
+    if (colok) { ga = ld4(a.gamma + lc); if (MODE == 1) gf = ld4(f.gamma + lc); }
+    f32x4 sga = {0, 0, 0, 0}, sba = sga, sgf = sga, sbf = sga;
+    const int row0 = blockIdx.x * rows_per_block;
+    for (int r = lr; r < rows_per_block; r += RPP) {
+        const int tok = row0 + r;
+        const bool ok = colok && tok < T;
+        const long e = (long)tok * d + lc;
+        f32x4 dy = {0, 0, 0, 0}, xa = dy, xf = dy;
+        float ra = 0.f, rf = 0.f;
+        if (ok) {
+            dy = ld4(dY + e);
+            if (MODE == 2) dy = dy * drop_mult4(a.drop, (uint64_t)e >> 2);
+            xa = ld4(a.xhat + e); ra = a.rstd[tok];
+            if (MODE == 1) { xf = ld4(f.xhat + e); rf = f.rstd[tok]; }
+        }
+        // branch a
+        const f32x4 dya = dy * a.in_scale;
+        const f32x4 g = dya * ga;
+        const float m1 = group_sum<LPR>(g.x + g.y + g.z + g.w) * invd;
+        const float m2 = group_sum<LPR>(g.x * xa.x + g.y * xa.y + g.z * xa.z + g.w * xa.w) * invd;
+        const f32x4 dza = ra * (g - m1 - xa * m2);
+        sga += dya * xa; sba += dya;
+        f32x4 dzsum = dza;
+        if (MODE == 1) {
+            const f32x4 dyf = dy * f.in_scale;
+            const f32x4 g2 = dyf * gf;
+            const float n1 = group_sum<LPR>(g2.x + g2.y + g2.z + g2.w) * invd;
+            const float n2 = group_sum<LPR>(g2.x * xf.x + g2.y * xf.y + g2.z * xf.z + g2.w * xf.w) * invd;
+            const f32x4 dzf = rf * (g2 - n1 - xf * n2);
+            sgf += dyf * xf; sbf += dyf;
+            dzsum += dzf;
+            if (ok) st4(f.dT + e, dzf * drop_mult4(f.drop, (uint64_t)e >> 2));
+        }
+        if (ok) {
+            st4(dZ + e, dzsum);
+            if (MODE != 2) st4(a.dT + e, dza * drop_mult4(a.drop, (uint64_t)e >> 2));
+        }
+    }
+    // block-level partials: sum the RPP row groups through LDS, fixed order -> deterministic
+    st4(&red[0][lr][lc], sga); st4(&red[1][lr][lc], sba);
+    if (MODE == 1) { st4(&red[2][lr][lc], sgf); st4(&red[3][lr][lc], sbf); }
+    __syncthreads();
+    constexpr int NV = (MODE == 1) ? 4 : 2;
+    for (int i = threadIdx.x; i < NV * LPR * 4; i += ROW_THREADS) {
+        const int which = i / (LPR * 4), c = i % (LPR * 4);
+        if (c >= d) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RPP; ++k) s += red[which][k][c];
+        float* dst = which == 0 ? a.pgamma : which == 1 ? a.pbeta : which == 2 ? f.pgamma : f.pbeta;
+        dst[(long)blockIdx.x * d + c] = s;
+    }
+}
+
+// =============================================================================================
+// K2 FrequencyLayer: low = irfft(trunc_cb(rfft(x))) as a pruned DFT held in LDS.
+//   X_k[c] = sum_t x[t,c] e^{-2 pi i k t / L}, k < cb;   low[t,c] = (1/L) sum_k w_k Re(X_k e^{+2 pi i k t/L})
+//   (the 1/sqrt(L) of the two 'ortho' transforms combine to 1/L).
+// One block per sequence; a row of d channels = LPR lanes x 4; the spectrum lives in LDS as
+// spec[k][re|im][d]; twiddle[j] = (cos, sin)(2 pi j / L) is a host-built table (fp64 -> fp32).
+//   forward : DSP = LN(Drop(low + beta^2 (x - low)) + x)                 src/model/bsarec.py:90-104
+//   backward: dX  = dXin + beta^2 dF + lowpass((1 - beta^2) dF),  dbeta = 2 beta sum dF (x - low)
+// =============================================================================================
+#define FREQ_KC 4
+template <int LPR, int NSRC, class Src>
+__device__ __forceinline__ void dft_spectrum(const Src& src, int L, int d, int cb, const float* __restrict__ tw,
+                                             float* __restrict__ spec /* [NSRC][cb][2][d] */,
+                                             float* __restrict__ part /* [RPP][NSRC][KC][2][LPR*4] */) {
+    constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4;
+    const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
+    const bool colok = lc < d;
+    for (int k0 = 0; k0 < cb; k0 += FREQ_KC) {
+        f32x4 re[NSRC][FREQ_KC], im[NSRC][FREQ_KC];
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+            for (int j = 0; j < FREQ_KC; ++j) { re[s][j] = f32x4{0, 0, 0, 0}; im[s][j] = f32x4{0, 0, 0, 0}; }
+        for (int t = lr; t < L; t += RPP) {
+            f32x4 x[NSRC];
+#pragma unroll
+            for (int s = 0; s < NSRC; ++s) x[s] = colok ? src(s, t, lc) : f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < FREQ_KC; ++j) {
+                const int k = k0 + j;
+                if (k < cb) {
+                    const int a = (int)(((long)k * t) % L);
+                    const float c = tw[2 * a], sn = tw[2 * a + 1];
+#pragma unroll
+                    for (int s = 0; s < NSRC; ++s) { re[s][j] += x[s] * c; im[s][j] -= x[s] * sn; }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+            for (int j = 0; j < FREQ_KC; ++j) {
+                st4(part + (((lr * NSRC + s) * FREQ_KC + j) * 2 + 0) * W + lc, re[s][j]);
+                st4(part + (((lr * NSRC + s) * FREQ_KC + j) * 2 + 1) * W + lc, im[s][j]);
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NSRC * FREQ_KC * 2 * W; i += ROW_THREADS) {
+            const int c = i % W, ri = (i / W) & 1, j = (i / (2 * W)) % FREQ_KC, s = i / (2 * W * FREQ_KC);
+            if (c < d && k0 + j < cb) {
+                float acc = 0.f;
+#pragma unroll
+                for (int g = 0; g < RPP; ++g) acc += part[(((g * NSRC + s) * FREQ_KC + j) * 2 + ri) * W + c];
+                spec[((long)(s * cb + k0 + j) * 2 + ri) * d + c] = acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ f32x4 dft_lowpass_at(const float* __restrict__ spec, int t, int lc, int L, int d, int cb,
+                                                const float* __restrict__ tw) {
+    f32x4 low = {0, 0, 0, 0};
+    for (int k = 0; k < cb; ++k) {
+        const int a = (int)(((long)k * t) % L);
+        const float w = (k == 0 || (2 * k == L)) ? 1.0f : 2.0f;
+        const float c = tw[2 * a] * w, sn = tw[2 * a + 1] * w;
+        low += ld4(spec + ((long)k * 2 + 0) * d + lc) * c - ld4(spec + ((long)k * 2 + 1) * d + lc) * sn;
+    }
+    return low * (1.0f / (float)L);
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(ROW_THREADS)
+freq_fwd_kernel(const float* __restrict__ X, const float* __restrict__ sqrt_beta, const float* __restrict__ gamma,
+                const float* __restrict__ beta, float eps, DropP drop, const float* __restrict__ twg, int L, int d,
+                int cb, float* __restrict__ DSP, float* __restrict__ xhat, float* __restrict__ rstd) {
+    constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* tw = fsm;                               // [2L] rounded up to 4
+    float* spec = tw + ((2 * L + 3) & ~3);         // [cb][2][d]
+    float* part = spec + (long)cb * 2 * d;         // [RPP][KC][2][W]
+    const int b = blockIdx.x;
+    const float* x = X + (long)b * L * d;
+    for (int i = threadIdx.x; i < 2 * L; i += ROW_THREADS) tw[i] = twg[i];
+    __syncthreads();
+    auto src = [&](int, int t, int lc) { return ld4(x + (long)t * d + lc); };
+    dft_spectrum<LPR, 1>(src, L, d, cb, tw, spec, part);
+
+    const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
+    const bool colok = lc < d;
+    f32x4 b2 = {0, 0, 0, 0}, g = b2, be = b2;
+    if (colok) { b2 = ld4(sqrt_beta + lc); b2 = b2 * b2; g = ld4(gamma + lc); be = ld4(beta + lc); }
+    const float invd = 1.0f / (float)d;
+    for (int t0 = 0; t0 < L; t0 += RPP) {
+        const int t = t0 + lr;
+        const bool ok = colok && t < L;
+        f32x4 v = {0, 0, 0, 0};
+        const long e = ((long)b * L + t) * d + lc;
+        if (ok) {
+            const f32x4 xv = ld4(x + (long)t * d + lc);
+            const f32x4 low = dft_lowpass_at(spec, t, lc, L, d, cb, tw);
+            const f32x4 fl = low + b2 * (xv - low);
+            v = fl * drop_mult4(drop, (uint64_t)e >> 2) + xv;
+        }
+        const float mean = group_sum<LPR>(v.x + v.y + v.z + v.w) * invd;
+        f32x4 dl = {0, 0, 0, 0};
+        if (ok) dl = v - mean;
+        const float var = group_sum<LPR>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * invd;
+        const float rs = 1.0f / sqrtf(var + eps);
+        if (ok) {
+            const f32x4 xh = dl * rs;
+            st4(xhat + e, xh);
+            st4(DSP + e, g * xh + be);
+            if (lc == 0) rstd[(long)b * L + t] = rs;
+        }
+    }
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(ROW_THREADS)
+freq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dF, const float* __restrict__ dXin,
+                const float* __restrict__ sqrt_beta, const float* __restrict__ twg, int L, int d, int cb,
+                float* __restrict__ dX, float* __restrict__ pbeta /* [B][d] */) {
+    constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* tw = fsm;
+    float* spec = tw + ((2 * L + 3) & ~3);         // [2][cb][2][d]: source 0 = x, source 1 = (1-beta^2) dF
+    float* part = spec + (long)2 * cb * 2 * d;     // [RPP][2][KC][2][W]
+    const int b = blockIdx.x;
+    const long base = (long)b * L * d;
+    for (int i = threadIdx.x; i < 2 * L; i += ROW_THREADS) tw[i] = twg[i];
+    __syncthreads();
+    const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
+    const bool colok = lc < d;
+    f32x4 bt = {0, 0, 0, 0};
+    if (colok) bt = ld4(sqrt_beta + lc);
+    const f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
+    auto src = [&](int s, int t, int c) {
+        const f32x4 v = ld4((s == 0 ? X : dF) + base + (long)t * d + c);
+        return s == 0 ? v : v * omb2;
+    };
+    dft_spectrum<LPR, 2>(src, L, d, cb, tw, spec, part);
+    f32x4 sb = {0, 0, 0, 0};
+    for (int t = lr; t < L; t += RPP) {
+        if (!colok) continue;
+        const long e = base + (long)t * d + lc;
+        const f32x4 xv = ld4(X + e), df = ld4(dF + e);
+        const f32x4 lowx = dft_lowpass_at(spec, t, lc, L, d, cb, tw);
+        const f32x4 lowg = dft_lowpass_at(spec + (long)cb * 2 * d, t, lc, L, d, cb, tw);
+        st4(dX + e, ld4(dXin + e) + b2 * df + lowg);
+        sb += df * (xv - lowx);
+    }
+    __syncthreads();
+    st4(part + lr * W + lc, sb);
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += ROW_THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < RPP; ++g) s += part[g * W + c];
+        pbeta[(long)b * d + c] = 2.0f * sqrt_beta[c] * s;
+    }
+}
+
+// =============================================================================================
+// K7 fused cross-entropy over the materialised logits row: lse, per-row loss, dlogits
+//   loss = mean_b (lse_b - logits[b, answer_b])                              src/model/bsarec.py:33-35
+// =============================================================================================
+__global__ void __launch_bounds__(ROW_THREADS)
+ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ answers, int V, int Vp, float inv_b,
+               float* __restrict__ dlogits, float* __restrict__ loss_rows) {
+    __shared__ float red[ROW_THREADS / 64];
+    __shared__ float bc;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (long)b * Vp;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += ROW_THREADS) mx = fmaxf(mx, row[v]);
+    mx = group_max<64>(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) { float m = red[0]; for (int i = 1; i < ROW_THREADS / 64; ++i) m = fmaxf(m, red[i]); bc = m; }
+    __syncthreads();
+    mx = bc;
+    float s = 0.f;
+    for (int v = tid; v < V; v += ROW_THREADS) s += expf(row[v] - mx);
+    s = group_sum<64>(s);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) { float t = 0.f; for (int i = 0; i < ROW_THREADS / 64; ++i) t += red[i]; bc = mx + logf(t); }
+    __syncthreads();
+    const float lse = bc;
+    int ans = (int)answers[b];
+    ans = ans < 0 ? 0 : (ans >= V ? V - 1 : ans);
+    for (int v = tid; v < Vp; v += ROW_THREADS) {
+        float g = 0.f;
+        if (v < V) g = (expf(row[v] - lse) - (v == ans ? 1.0f : 0.0f)) * inv_b;
+        dlogits[(long)b * Vp + v] = g;
+    }
+    if (tid == 0) loss_rows[b] = lse - row[ans];
+}
+
+// gradient of the last layer's output: zero everywhere except position L-1 of every sequence, where
+// it is the split-K sum of dlogits . E                                   (src/model/bsarec.py:32)
+__global__ void __launch_bounds__(ROW_THREADS)
+dlast_kernel(const float* __restrict__ slabs, int nsplit, long slab_stride, int T, int L, int d,
+             float* __restrict__ dX) {
+    const long i = (long)blockIdx.x * ROW_THREADS + threadIdx.x;       // float4 index
+    const long n4 = (long)T * d / 4;
+    if (i >= n4) return;
+    const long e = i * 4;
+    const int tok = (int)(e / d), c = (int)(e % d);
+    f32x4 v = {0, 0, 0, 0};
+    if (tok % L == L - 1) {
+        const int b = tok / L;
+        for (int s = 0; s < nsplit; ++s) v += ld4(slabs + s * slab_stride + (long)b * d + c);
+    }
+    st4(dX + e, v);
+}
+
+// =============================================================================================
+// embedding-gradient tail: dPos[t] = sum_b de[b,t]  (deterministic), dE[ids] += de for ids != 0
+// (padding_idx = 0 suppresses only the lookup gradient, src/model/_abstract_model.py:10).  The dense
+// logits-path dE is already in place; rows are added with full-row (>= 64 B contiguous) f32 atomics.
+// =============================================================================================
+template <int LPR>
+__global__ void __launch_bounds__(ROW_THREADS)
+embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, int B, int L, int d,
+                 float* __restrict__ dE, float* __restrict__ dPos, int scatter_blocks) {
+    constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4;
+    __shared__ float red[RPP][W];
+    const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
+    const bool colok = lc < d;
+    if ((int)blockIdx.x < scatter_blocks) {
+        const int tok = blockIdx.x * RPP + lr;
+        if (tok < B * L && colok) {
+            const int id = ids32[tok];
+            if (id != 0) {
+                const f32x4 g = ld4(de + (long)tok * d + lc);
+                float* dst = dE + (long)id * d + lc;
+                unsafeAtomicAdd(dst + 0, g.x); unsafeAtomicAdd(dst + 1, g.y); unsafeAtomicAdd(dst + 2, g.z); unsafeAtomicAdd(dst + 3, g.w);
+            }
+        }
+        return;
+    }
+    const int t = blockIdx.x - scatter_blocks;       // one block per position
+    f32x4 s = {0, 0, 0, 0};
+    if (colok)
+        for (int b = lr; b < B; b += RPP) s += ld4(de + ((long)b * L + t) * d + lc);
+    st4(&red[lr][lc], s);
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += ROW_THREADS) {
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < RPP; ++g) a += red[g][c];
+        dPos[(long)t * d + c] = a;
+    }
+}
+
+// =============================================================================================
+// deterministic second-stage reductions: dst[i] = scale * sum_s src[s*stride + i]
+// =============================================================================================
+struct ReduceJob { const float* src; float* dst; int nsplit; int len; long stride; float scale; int pad; };
+
+__global__ void __launch_bounds__(ROW_THREADS)
+multi_reduce_kernel(const ReduceJob* __restrict__ jobs) {
+    const ReduceJob j = jobs[blockIdx.y];
+    const int i = blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (i >= j.len) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < j.nsplit; s += 4) {
+        a0 += j.src[(long)s * j.stride + i];
+        a1 += j.src[(long)(s + 1) * j.stride + i];
+        a2 += j.src[(long)(s + 2) * j.stride + i];
+        a3 += j.src[(long)(s + 3) * j.stride + i];
+    }
+    for (; s < j.nsplit; ++s) a0 += j.src[(long)s * j.stride + i];
+    j.dst[i] = ((a0 + a1) + (a2 + a3)) * j.scale;
+}
+
+// =============================================================================================
+// device-resident step state (lets a captured hipGraph replay with fresh dropout masks / Adam t):
+//   u64 state[0] = seed, [1] = forward-step counter, [2] = Adam t; f32 view of [3] = {lr/bc1, sqrt(bc2)}
+// =============================================================================================
+__global__ void step_begin_kernel(uint64_t* state) { state[1] += 1; }
+
+__global__ void adam_tick_kernel(uint64_t* state, double lr, double b1, double b2) {
+    const uint64_t t = state[2] + 1;
+    state[2] = t;
+    float* f = reinterpret_cast<float*>(state + 3);
+    f[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
+    f[1] = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+
+// K9 fused Adam over the flat parameter arena (torch.optim.Adam semantics, src/trainers.py:27-28):
+//   g += wd*w; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void __launch_bounds__(ROW_THREADS)
+adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n4,
+            const uint64_t* __restrict__ state, float b1, float b2, float eps, float wd, float gscale) {
+    const float* f = reinterpret_cast<const float*>(state + 3);
+    const float step_size = f[0], bc2s = f[1];
+    for (long i = (long)blockIdx.x * ROW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * ROW_THREADS) {
+        f32x4 wi = ld4(w + 4 * i), gi = ld4(g + 4 * i) * gscale, mi = ld4(m + 4 * i), vi = ld4(v + 4 * i);
+        if (wd != 0.f) gi += wd * wi;
+        mi = b1 * mi + (1.0f - b1) * gi;
+        vi = b2 * vi + (1.0f - b2) * gi * gi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wi[k] -= step_size * (mi[k] / (sqrtf(vi[k]) / bc2s + eps));
+        st4(w + 4 * i, wi); st4(m + 4 * i, mi); st4(v + 4 * i, vi);
+    }
+}
+
+__global__ void __launch_bounds__(ROW_THREADS)
+loss_mean_kernel(const float* __restrict__ rows, int B, float* __restrict__ out) {
+    __shared__ float red[ROW_THREADS];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < B; i += ROW_THREADS) s += rows[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = ROW_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (float)B;
+}

@@ -1,0 +1,334 @@
+"""Host-side mirror of the reference model API over the gfx950 C ABI.
+
+``BSARecModel(args)`` keeps the reference's constructor, attribute and state_dict contract
+(src/model/bsarec.py:7-37, src/model/_abstract_model.py:6-79; the 4 + 19 N state_dict keys of
+SURVEY 8b) so the reference's ``main.py`` / ``Trainer`` / checkpoints drop in, while every FLOP runs
+in ``libbsarec_hip.so``.  PyTorch is only the allocator, the stream and the nn.Module shell:
+
+* all parameters are views of ONE flat fp32 arena, their gradients views of a second one, so the
+  optimiser is a single fused kernel and the data-parallel exchange a single all-reduce;
+* activations / scratch live in one workspace tensor carved by the library's launch plan;
+* there is no fallback: constructing works on CPU (state_dict plumbing), running needs the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+def param_shapes(args) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict keys and shapes in the reference's registration order."""
+    d, Lq, V = args.hidden_size, args.max_seq_length, args.item_size
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["item_embeddings.weight"] = (V, d)
+    s["position_embeddings.weight"] = (Lq, d)
+    s["LayerNorm.weight"] = (d,)
+    s["LayerNorm.bias"] = (d,)
+    for l in range(args.num_hidden_layers):
+        p = f"item_encoder.blocks.{l}."
+        s[p + "layer.filter_layer.sqrt_beta"] = (1, 1, d)
+        s[p + "layer.filter_layer.LayerNorm.weight"] = (d,)
+        s[p + "layer.filter_layer.LayerNorm.bias"] = (d,)
+        for nm in ("query", "key", "value", "dense"):
+            s[p + f"layer.attention_layer.{nm}.weight"] = (d, d)
+            s[p + f"layer.attention_layer.{nm}.bias"] = (d,)
+        s[p + "layer.attention_layer.LayerNorm.weight"] = (d,)
+        s[p + "layer.attention_layer.LayerNorm.bias"] = (d,)
+        s[p + "feed_forward.dense_1.weight"] = (4 * d, d)
+        s[p + "feed_forward.dense_1.bias"] = (4 * d,)
+        s[p + "feed_forward.dense_2.weight"] = (d, 4 * d)
+        s[p + "feed_forward.dense_2.bias"] = (d,)
+        s[p + "feed_forward.LayerNorm.weight"] = (d,)
+        s[p + "feed_forward.LayerNorm.bias"] = (d,)
+    return s
+
+
+class _Bag(nn.Module):
+    """Attribute container so that parameter paths match the reference's module tree."""
+
+
+def _twiddle(Lq: int) -> torch.Tensor:
+    j = np.arange(Lq, dtype=np.float64)
+    tw = np.stack([np.cos(2.0 * np.pi * j / Lq), np.sin(2.0 * np.pi * j / Lq)], axis=1)
+    return torch.from_numpy(tw.astype(np.float32).reshape(-1).copy())
+
+
+class _Plan:
+    """One launch plan (fixed batch size) + the workspace tensor it carves."""
+
+    def __init__(self, model: "BSARecModel", batch: int):
+        lib = L.load()
+        a = model.args
+        self.cfg = L.Config(batch, a.max_seq_length, a.hidden_size, a.num_attention_heads, a.num_hidden_layers,
+                            a.item_size, model.cutoff_bins, float(a.alpha), 1e-12, float(a.hidden_dropout_prob),
+                            float(a.attention_probs_dropout_prob))
+        nbytes = lib.bsarec_workspace_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise ValueError("configuration not supported by libbsarec_hip (see include/bsarec_hip.h limits: "
+                             "L <= 256, hidden <= 256 and % 4 == 0, head size % 4 == 0, cutoff_bins*hidden <= 8192)")
+        dev = model._arena.device
+        self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        off = (-self.ws.data_ptr()) % 256
+        self.ws = self.ws[off:off + nbytes]
+        self.ws.zero_()
+        self.batch = batch
+        self.handle = C.c_void_p()
+        pt, gt = model._tensor_struct(model._arena), model._tensor_struct(model._garena)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(lib.bsarec_plan_create(C.byref(self.handle), C.byref(self.cfg), C.byref(pt), C.byref(gt),
+                                       self.ws.data_ptr(), nbytes, model._state.data_ptr(),
+                                       model._twiddle.data_ptr(), stream), "bsarec_plan_create")
+        self.lib = lib
+
+    def view(self, buf: int, layer: int, shape) -> torch.Tensor:
+        off = self.lib.bsarec_buffer_offset(self.handle, buf, layer)
+        if off < 0:
+            raise IndexError("no such buffer")
+        n = int(np.prod(shape)) * 4
+        return self.ws[off:off + n].view(torch.float32).view(*shape)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.bsarec_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class _LossFn(torch.autograd.Function):
+    """calculate_loss as one autograd node: forward+loss kernels now, the whole backward chain when
+    autograd calls back (src/trainers.py:103-106)."""
+
+    @staticmethod
+    def forward(ctx, model, ids, answers, *params):
+        plan = model._run_forward(ids, train=model.training, new_step=model.training)
+        model._run_loss(plan, answers)
+        ctx.model, ctx.plan = model, plan
+        return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, plan = ctx.model, ctx.plan
+        model._run_backward(plan)
+        g = model._garena * gout
+        return (None, None, None) + tuple(g[o:o + n].view(shp) for (o, n, shp) in model._slices.values())
+
+
+class BSARecModel(nn.Module):
+    """Drop-in for ``MODEL_DICT['bsarec'](args=args)`` (src/main.py:31)."""
+
+    def __init__(self, args):
+        super().__init__()
+        if args.hidden_size % args.num_attention_heads != 0:           # src/model/_modules.py:79-82
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (args.hidden_size, args.num_attention_heads))
+        if getattr(args, "hidden_act", "gelu") != "gelu":
+            raise ValueError("bsarec_amd implements the reference default hidden_act='gelu' only")
+        self.args = args
+        self.batch_size = getattr(args, "batch_size", 256)              # stored, unused (as in the reference)
+        self.cutoff_bins = min(args.c // 2 + 1, args.max_seq_length // 2 + 1)   # src/model/bsarec.py:87,96
+        shapes = param_shapes(args)
+        self._slices: "OrderedDict[str, Tuple[int, int, Tuple[int, ...]]]" = OrderedDict()
+        off = 0
+        for k, shp in shapes.items():
+            n = int(np.prod(shp))
+            self._slices[k] = (off, n, shp)
+            off += n
+        self._numel = off
+        arena = torch.zeros(off, dtype=torch.float32)
+        self._build_tree(arena)
+        self._install_arena(arena)
+        self.init_weights()
+        self._plans: Dict[Tuple[int, str], _Plan] = {}
+        self._seed = int(getattr(args, "seed", 42))
+
+    # ---- module tree with the reference's parameter paths -------------------------------------
+    def _build_tree(self, arena):
+        for key, (o, n, shp) in self._slices.items():
+            parts = key.split(".")
+            mod = self
+            for name in parts[:-1]:
+                if not hasattr(mod, name):
+                    mod.add_module(name, _Bag())
+                mod = getattr(mod, name)
+            mod.register_parameter(parts[-1], nn.Parameter(arena[o:o + n].view(shp)))
+
+    def _param_by_key(self, key):
+        mod = self
+        parts = key.split(".")
+        for name in parts[:-1]:
+            mod = getattr(mod, name)
+        return mod._parameters[parts[-1]]
+
+    def _install_arena(self, arena):
+        """(Re)point every parameter at its slice of ``arena``; allocate grad arena + device state."""
+        self._arena = arena
+        self._garena = torch.zeros_like(arena)
+        for key, (o, n, shp) in self._slices.items():
+            p = self._param_by_key(key)
+            p.data = arena[o:o + n].view(shp)
+            p.grad = None
+        self._state = torch.zeros(8, dtype=torch.int64, device=arena.device)
+        self._twiddle = _twiddle(self.args.max_seq_length).to(arena.device)
+        self._plans = {}
+        self._adam = None
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        # .cuda()/.cpu()/.to() re-allocated every parameter separately: gather them back into one arena
+        ref = self._param_by_key("item_embeddings.weight")
+        arena = torch.empty(self._numel, dtype=torch.float32, device=ref.device)
+        for key, (o, n, shp) in self._slices.items():
+            arena[o:o + n] = self._param_by_key(key).data.reshape(-1).to(torch.float32)
+        seed = self._seed if hasattr(self, "_seed") else 42
+        self._install_arena(arena)
+        self._seed = seed
+        return out
+
+    def init_weights(self, module=None):
+        """src/model/_abstract_model.py:26-39 + src/model/bsarec.py:88."""
+        std = self.args.initializer_range
+        with torch.no_grad():
+            for key, (o, n, shp) in self._slices.items():
+                p = self._param_by_key(key)
+                if key.endswith("sqrt_beta"):
+                    p.normal_(0.0, 1.0)
+                elif "LayerNorm.weight" in key:
+                    p.fill_(1.0)
+                elif key.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.normal_(0.0, std)          # Linear / Embedding weights, padding row 0 included
+
+    # ---- C ABI plumbing -----------------------------------------------------------------------
+    def _tensor_struct(self, arena) -> L.Tensors:
+        t = L.Tensors()
+        base = arena.data_ptr()
+
+        def ptr(key):
+            return base + 4 * self._slices[key][0]
+        for f, key in L.TOP_KEYS.items():
+            setattr(t, f, ptr(key))
+        for l in range(self.args.num_hidden_layers):
+            for f, suffix in L.LAYER_KEYS.items():
+                setattr(t.layer[l], f, ptr(f"item_encoder.blocks.{l}.{suffix}"))
+        return t
+
+    def _require_gpu(self):
+        if self._arena.device.type != "cuda":
+            raise RuntimeError("bsarec_amd runs on MI355X only: move the model with .cuda() "
+                               "(there is no CPU fallback; the CPU oracle lives under oracle/ for tests)")
+
+    def set_seed(self, seed: int, rank: int = 0):
+        """Seed of the device-side Philox dropout stream (rank-decorrelated for data parallel)."""
+        self._seed = int(seed)
+        s = (int(seed) ^ (rank * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
+        self._state[0] = s
+
+    def _plan(self, batch: int) -> _Plan:
+        self._require_gpu()
+        key = (batch, str(self._arena.device))
+        if key not in self._plans:
+            if int(self._state[0].item()) == 0:
+                self.set_seed(self._seed)
+            self._plans[key] = _Plan(self, batch)
+        return self._plans[key]
+
+    def _stream(self):
+        return torch.cuda.current_stream(self._arena.device).cuda_stream
+
+    def _run_forward(self, input_ids, train: bool, new_step: bool) -> _Plan:
+        if input_ids.dim() != 2 or input_ids.shape[1] != self.args.max_seq_length:
+            raise ValueError("input_ids must be [B, max_seq_length]")
+        ids = input_ids.to(device=self._arena.device, dtype=torch.int64).contiguous()
+        plan = self._plan(ids.shape[0])
+        lib, st = plan.lib, self._stream()
+        if new_step:
+            L.check(lib.bsarec_step_begin(plan.handle, st), "bsarec_step_begin")
+        L.check(lib.bsarec_forward(plan.handle, ids.data_ptr(), 1 if train else 0, st), "bsarec_forward")
+        plan._ids_keepalive = ids
+        return plan
+
+    def _run_loss(self, plan: _Plan, answers):
+        ans = answers.to(device=self._arena.device, dtype=torch.int64).contiguous()
+        L.check(plan.lib.bsarec_loss(plan.handle, ans.data_ptr(), self._stream()), "bsarec_loss")
+        plan._ans_keepalive = ans
+
+    def _run_backward(self, plan: _Plan):
+        L.check(plan.lib.bsarec_backward(plan.handle, self._stream()), "bsarec_backward")
+
+    # ---- reference model API --------------------------------------------------------------------
+    def forward(self, input_ids, user_ids=None, all_sequence_output=False):
+        """src/model/bsarec.py:16-28.  Returns detached tensors (copies of the workspace buffers);
+        gradients flow through :meth:`calculate_loss`."""
+        plan = self._run_forward(input_ids, train=self.training, new_step=self.training)
+        B, Lq, d = input_ids.shape[0], self.args.max_seq_length, self.args.hidden_size
+        if all_sequence_output:
+            return [plan.view(L.BUF_LAYER_OUT, l, (B, Lq, d)).clone() for l in range(self.args.num_hidden_layers + 1)]
+        return plan.view(L.BUF_LAYER_OUT, self.args.num_hidden_layers, (B, Lq, d)).clone()
+
+    def predict(self, input_ids, user_ids=None, all_sequence_output=False):
+        """src/model/_abstract_model.py:74-75."""
+        return self.forward(input_ids, user_ids, all_sequence_output)
+
+    def calculate_loss(self, input_ids, answers, neg_answers=None, same_target=None, user_ids=None):
+        """src/model/bsarec.py:30-37: 0-d loss tensor; ``.backward()`` fills every parameter's grad."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _LossFn.apply(self, input_ids, answers, *self.parameters())
+        plan = self._run_forward(input_ids, train=self.training, new_step=self.training)
+        self._run_loss(plan, answers)
+        return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
+
+    def full_logits(self, input_ids) -> torch.Tensor:
+        """Last-position scores over the whole catalogue (Trainer.predict_full of the last position,
+        src/trainers.py:62-68,126-129) without leaving the device."""
+        plan = self._run_forward(input_ids, train=False, new_step=False)
+        L.check(plan.lib.bsarec_logits(plan.handle, self._stream()), "bsarec_logits")
+        V = self.args.item_size
+        Vp = (V + 3) // 4 * 4
+        return plan.view(L.BUF_LOGITS, 0, (input_ids.shape[0], Vp))[:, :V]
+
+    # ---- fused training step (used by bsarec_amd.trainer.Trainer) ------------------------------
+    def configure_adam(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self._require_gpu()
+        self._adam = dict(lr=float(lr), b1=float(betas[0]), b2=float(betas[1]), eps=float(eps), wd=float(weight_decay),
+                          m=torch.zeros_like(self._arena), v=torch.zeros_like(self._arena))
+        self._state[2] = 0
+
+    def train_step(self, input_ids, answers) -> torch.Tensor:
+        """step_begin + forward + loss + backward + Adam in one C call (src/trainers.py:100-107).
+        Returns a view of the device loss scalar (no host sync)."""
+        if self._adam is None:
+            raise RuntimeError("call configure_adam() first")
+        ids = input_ids.to(device=self._arena.device, dtype=torch.int64).contiguous()
+        ans = answers.to(device=self._arena.device, dtype=torch.int64).contiguous()
+        plan = self._plan(ids.shape[0])
+        a = self._adam
+        L.check(plan.lib.bsarec_train_step(plan.handle, ids.data_ptr(), ans.data_ptr(), self._arena.data_ptr(),
+                                           self._garena.data_ptr(), a["m"].data_ptr(), a["v"].data_ptr(), self._numel,
+                                           a["lr"], a["b1"], a["b2"], a["eps"], a["wd"], self._stream()),
+                "bsarec_train_step")
+        plan._ids_keepalive, plan._ans_keepalive = ids, ans
+        return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
+    def adam_step(self, grad_scale: float = 1.0):
+        """Fused Adam over the flat arenas (after an external gradient all-reduce)."""
+        a = self._adam
+        L.check(L.load().bsarec_adam_step(self._arena.data_ptr(), self._garena.data_ptr(), a["m"].data_ptr(),
+                                          a["v"].data_ptr(), self._numel, self._state.data_ptr(), a["lr"], a["b1"],
+                                          a["b2"], a["eps"], a["wd"], float(grad_scale), self._stream()),
+                "bsarec_adam_step")
+
+    def grad_views(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((k, self._garena[o:o + n].view(shp)) for k, (o, n, shp) in self._slices.items())
+
+
+MODEL_DICT = {"bsarec": BSARecModel}       # src/model/__init__.py:10-19 (the one entry on the hot path)

@@ -1,0 +1,156 @@
+/* bsarec_hip.h -- C ABI of the MI355X (gfx950) BSARec training hot path.
+ *
+ * The reference (Sun-Sir/BSARec) is pure Python/PyTorch and has no FFI: the seam this library
+ * slots under is the Python object protocol between Trainer and the model
+ * (src/trainers.py:94-116 -> src/model/bsarec.py:16-37).  Each entry point below names the
+ * reference code it replaces.  Conventions:
+ *   - plain pointers and sizes only; every device buffer is allocated and owned by the caller
+ *     (PyTorch in the shipped host code); the library never allocates or frees device memory;
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*), never synchronises, and
+ *     can therefore be captured into a hipGraph;
+ *   - return value: 0 = OK, < 0 = invalid argument / unsupported shape (nothing was launched),
+ *     > 0 = hipError_t of a failed launch;
+ *   - fp32 everywhere (the reference's arithmetic type); ids and answers are int64 as produced by
+ *     the reference DataLoader (src/dataset.py:108-115).
+ */
+#ifndef BSAREC_HIP_H
+#define BSAREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSAREC_MAX_LAYERS 16
+#define BSAREC_ABI_VERSION 1
+
+/* Hyper-parameters the reference model reads from `args`
+ * (src/utils.py:83-96; src/model/bsarec.py:71-88; src/model/_modules.py:79-87). */
+typedef struct {
+    int batch;          /* B: sequences per call (src/utils.py:67) */
+    int seq_len;        /* L = max_seq_length */
+    int hidden;         /* d = hidden_size, multiple of 4, <= 256 */
+    int heads;          /* num_attention_heads; d/heads multiple of 4 */
+    int layers;         /* num_hidden_layers, <= BSAREC_MAX_LAYERS */
+    int item_size;      /* V = max item id + 1 (row 0 = padding, still a class) */
+    int cutoff_bins;    /* min(c//2 + 1, L//2 + 1): rFFT bins kept by FrequencyLayer */
+    float alpha;        /* BSARecLayer mix (src/model/bsarec.py:78) */
+    float ln_eps;       /* 1e-12 */
+    float p_hidden;     /* hidden_dropout_prob */
+    float p_attn;       /* attention_probs_dropout_prob */
+} bsarec_config_t;
+
+/* The 19 tensors of one BSARecBlock, in state_dict order
+ * (item_encoder.blocks.{l}.layer.filter_layer.* , .attention_layer.* , .feed_forward.*). */
+typedef struct {
+    float *sqrt_beta, *filter_ln_w, *filter_ln_b;
+    float *query_w, *query_b, *key_w, *key_b, *value_w, *value_b, *dense_w, *dense_b;
+    float *attn_ln_w, *attn_ln_b;
+    float *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b, *ffn_ln_w, *ffn_ln_b;
+} bsarec_layer_t;
+
+/* All 4 + 19 N tensors (parameters, or their gradients) as device pointers.  Linear weights are
+ * [out, in] row-major exactly as nn.Linear stores them. */
+typedef struct {
+    float *item_emb;    /* [V, d]  item_embeddings.weight */
+    float *pos_emb;     /* [L, d]  position_embeddings.weight */
+    float *ln_w, *ln_b; /* [d]     LayerNorm.{weight,bias} */
+    bsarec_layer_t layer[BSAREC_MAX_LAYERS];
+} bsarec_tensors_t;
+
+/* Named device buffers inside the workspace (byte offsets via bsarec_buffer_offset). */
+enum {
+    BSAREC_BUF_LAYER_OUT = 0,  /* [B,L,d]   output of layer l-1 (l = 0: embedding output), l in [0, N] */
+    BSAREC_BUF_LOGITS = 1,     /* [B,Vp]    full-catalogue logits, Vp = 4*ceil(V/4), pad columns = 0 */
+    BSAREC_BUF_LOSS = 2,       /* [1]       mean cross-entropy */
+    BSAREC_BUF_DSP = 3,        /* [B,L,d]   FrequencyLayer output of layer l */
+    BSAREC_BUF_HMIX = 4,       /* [B,L,d]   alpha*dsp + (1-alpha)*gsp of layer l */
+    BSAREC_BUF_PROBS = 5,      /* [B,h,L,Lp] attention probabilities of layer l (before dropout) */
+    BSAREC_BUF_DLAYER_IN = 6,  /* [B,L,d]   gradient w.r.t. layer output l (ping-pong pair: only l = 0, 1 survive backward) */
+    BSAREC_BUF_LOSS_ROWS = 7,  /* [B]       per-sequence cross-entropy */
+    BSAREC_BUF_CTX = 8         /* [B,L,d]   attention context of layer l */
+};
+
+typedef struct bsarec_plan bsarec_plan_t;   /* host-side launch plan (no device memory of its own) */
+
+int bsarec_abi_version(void);
+
+/* Bytes of device workspace a plan for `cfg` needs (activations kept for backward, scratch,
+ * split-K slabs, reduction job table).  0 if cfg is unsupported. */
+size_t bsarec_workspace_bytes(const bsarec_config_t *cfg);
+
+/* Device step state: 8 x uint64.  [0] seed of the Philox dropout stream, [1] forward-step counter,
+ * [2] Adam step t, [3] two packed floats written by bsarec_adam_step.  The caller zero-initialises
+ * it and sets [0]; kernels read/advance it on the device so a captured graph replays correctly. */
+#define BSAREC_STATE_BYTES 64
+
+/* Build a launch plan.  `params`/`grads` hold device pointers (copied into the plan); `workspace`
+ * must hold bsarec_workspace_bytes(cfg) bytes, 256-byte aligned; `twiddle` is the float[2L] table
+ * (cos, sin)(2 pi j / L) built on the host in double precision.  Enqueues one small H2D copy of the
+ * reduction job table on `stream`.  Replaces: model construction wiring of src/model/bsarec.py:8-14. */
+int bsarec_plan_create(bsarec_plan_t **out, const bsarec_config_t *cfg, const bsarec_tensors_t *params,
+                       const bsarec_tensors_t *grads, void *workspace, size_t workspace_bytes,
+                       void *state, const float *twiddle, void *stream);
+void bsarec_plan_destroy(bsarec_plan_t *plan);
+
+/* Byte offset of a named buffer inside the workspace, or -1. */
+long bsarec_buffer_offset(const bsarec_plan_t *plan, int buffer, int layer);
+
+/* Advance the forward-step counter (new dropout masks).  Call once per training step. */
+int bsarec_step_begin(bsarec_plan_t *plan, void *stream);
+
+/* BSARecModel.forward(input_ids, all_sequence_output=True)   (src/model/bsarec.py:16-28):
+ * ids int64[B,L] (left-padded with 0) -> layer outputs in BSAREC_BUF_LAYER_OUT[0..N].
+ * train != 0 applies dropout (model.train()), 0 is model.eval(). */
+int bsarec_forward(bsarec_plan_t *plan, const int64_t *ids, int train, void *stream);
+
+/* The rest of BSARecModel.calculate_loss (src/model/bsarec.py:32-35) on the forward's result:
+ * logits = h[:, -1, :] @ E^T, mean CE against answers int64[B]; also prepares dlogits. */
+int bsarec_loss(bsarec_plan_t *plan, const int64_t *answers, void *stream);
+
+/* logits only (Trainer.predict_full, src/trainers.py:62-68). */
+int bsarec_logits(bsarec_plan_t *plan, void *stream);
+
+/* loss.backward() (src/trainers.py:106): gradients of all tensors -> `grads` (overwritten, not
+ * accumulated).  Must follow bsarec_forward(train as given there) + bsarec_loss on the same plan. */
+int bsarec_backward(bsarec_plan_t *plan, void *stream);
+
+/* torch.optim.Adam step (src/trainers.py:27-28,107) over flat arenas of n floats (n % 4 == 0):
+ * g is scaled by grad_scale first (1/world_size after a summing all-reduce). */
+int bsarec_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, void *state,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                     void *stream);
+
+/* Trainer.iteration's per-batch body (src/trainers.py:100-107) in one call:
+ * step_begin + forward(train) + loss + backward + Adam. */
+int bsarec_train_step(bsarec_plan_t *plan, const int64_t *ids, const int64_t *answers, float *params_flat,
+                      const float *grads_flat, float *exp_avg, float *exp_avg_sq, long n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, void *stream);
+
+/* Stand-alone FrequencyLayer (src/model/bsarec.py:90-104) for per-op parity tests:
+ * y = LN(Drop(low + beta^2 (x - low)) + x); backward given dy. */
+int bsarec_freq_layer_fwd(const float *x, const float *sqrt_beta, const float *ln_w, const float *ln_b,
+                          const float *twiddle, int B, int L, int d, int cutoff_bins, float eps, float p_drop,
+                          const void *state, int site, float *y, float *xhat, float *rstd, void *stream);
+long bsarec_freq_layer_bwd_scratch_floats(int B, int L, int d);
+int bsarec_freq_layer_bwd(const float *x, const float *dy, const float *xhat, const float *rstd,
+                          const float *sqrt_beta, const float *ln_w, const float *twiddle, int B, int L, int d,
+                          int cutoff_bins, float p_drop, const void *state, int site,
+                          float *scratch /* bsarec_freq_layer_bwd_scratch_floats(B,L,d) floats */,
+                          float *dx, float *dsqrt_beta, float *dln_w, float *dln_b, void *stream);
+
+/* Tag kernel launches of one id with hipEvents for in-process roofline timing (bench.py):
+ * when set, every launch of kernel class `kclass` (see BSAREC_K_*) on the next calls is bracketed
+ * by hipEventRecord on the launch stream; bsarec_profile_read returns the summed milliseconds and
+ * launch count, then resets.  Not for use under graph capture. */
+enum { BSAREC_K_NONE = 0, BSAREC_K_FFN1 = 1, BSAREC_K_FFN2 = 2, BSAREC_K_QKV = 3, BSAREC_K_LOGITS = 4,
+       BSAREC_K_DU = 5, BSAREC_K_DW1 = 6 };
+int bsarec_profile_select(int kclass);
+int bsarec_profile_read(double *ms_total, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSAREC_HIP_H */

@@ -1,0 +1,145 @@
+"""HIP path vs the reference's golden vectors and vs the CPU oracle (through the C ABI).
+Needs a real MI355X: run with  pytest -m gpu."""
+import argparse
+import json
+
+import numpy as np
+import pytest
+
+from conftest import E2E_CASES, load_e2e, rel_l2
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def make_args(cfg, **kw):
+    a = argparse.Namespace(
+        item_size=cfg.item_size, hidden_size=cfg.hidden_size, max_seq_length=cfg.max_seq_length, batch_size=256,
+        hidden_dropout_prob=cfg.hidden_dropout_prob, attention_probs_dropout_prob=cfg.attention_probs_dropout_prob,
+        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads, hidden_act="gelu",
+        initializer_range=cfg.initializer_range, c=cfg.c, alpha=cfg.alpha, seed=42)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def build_model(cfg, params, **kw):
+    from bsarec_amd import BSARecModel
+    m = BSARecModel(make_args(cfg, **kw))
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()})
+    return m.cuda()
+
+
+def check_outputs(outs_gpu, outs_ref, ids, tol_real, tol_pad):
+    real = ids > 0
+    for i, (g, r) in enumerate(zip(outs_gpu, outs_ref)):
+        g = g.cpu().numpy()
+        assert np.isfinite(g).all()
+        err = np.abs(g - r)
+        assert err[real].max(initial=0.0) <= tol_real, (i, err[real].max())
+        assert err.max() <= tol_pad, (i, err.max())
+
+
+def check_grads(model, grads_ref, tol=1e-4, skip=()):
+    G = model.grad_views()
+    assert set(G) == set(grads_ref)
+    worst = {}
+    for k, r in grads_ref.items():
+        g = G[k].cpu().numpy()
+        assert np.isfinite(g).all(), k
+        if k.endswith("key.bias"):                       # true gradient is zero
+            assert np.abs(g).max() <= 1e-6, (k, np.abs(g).max())
+            continue
+        worst[k] = rel_l2(g, r)
+    bad = {k: v for k, v in worst.items() if v > tol and k not in skip}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", E2E_CASES)
+def test_forward_loss_grads_vs_reference_golden(name):
+    """Reference (imported PyTorch) outputs: all layer outputs, logits, loss, all gradients."""
+    cfg, params, grads, _, z = load_e2e(name)
+    model = build_model(cfg, params)
+    model.train()                                        # golden was made in train mode with p = 0
+    ids = torch.from_numpy(z["ids"]).cuda()
+    ans = torch.from_numpy(z["answers"]).cuda()
+    outs = model.forward(ids, all_sequence_output=True)
+    check_outputs(outs, [z[f"out/{i}"] for i in range(len(outs))], z["ids"], 2e-5, 5e-4)
+    logits = model.full_logits(ids).cpu().numpy()
+    assert np.abs(logits - z["logits"]).max() <= 1e-3 * np.abs(z["logits"]).max()      # north-star gate
+    assert np.abs(logits - z["logits"]).max() <= 2e-5
+    loss = model.calculate_loss(ids, ans, None, None, None)
+    assert abs(loss.item() - float(z["loss"])) <= 2e-6 * abs(float(z["loss"]))
+    loss.backward()
+    check_grads(model, grads)
+    # autograd delivered the same thing into .grad
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.equal(p.grad, model.grad_views()[k]), k
+
+
+@pytest.mark.parametrize("name", E2E_CASES[:3])
+def test_three_fused_adam_steps_vs_reference(name):
+    cfg, params, _, after, z = load_e2e(name)
+    model = build_model(cfg, params)
+    model.train()
+    model.configure_adam(lr=1e-3)
+    ids = torch.from_numpy(z["ids"]).cuda()
+    ans = torch.from_numpy(z["answers"]).cuda()
+    losses = [model.train_step(ids, ans).item() for _ in range(3)]
+    np.testing.assert_allclose(losses, z["adam_losses"], rtol=5e-6)
+    sd = model.state_dict()
+    for k, a in after.items():
+        got = sd[k].cpu().numpy()
+        if k.endswith("key.bias"):
+            assert np.abs(got - a).max() <= 3.5e-3
+            continue
+        bad = np.abs(got - a) > 2e-5
+        assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - a).max())
+
+
+@pytest.mark.parametrize("name,B", [("A_d64_L50_h2", 37), ("C_d32_L12_h4", 70), ("D_d128_L200_h4", 5)])
+def test_dropout_training_step_vs_oracle(name, B):
+    """Dropout ON (p = 0.5 / 0.3): the oracle draws the same Philox masks, so forward, loss and every
+    gradient must agree; ragged batch sizes exercise the tile tails."""
+    from oracle import bsarec_oracle as O
+    cfg, params, _, _, _ = load_e2e(name)
+    cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob = 0.5, 0.3
+    rng = np.random.default_rng(5)
+    L, V = cfg.max_seq_length, cfg.item_size
+    ids = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        n = int(rng.integers(0, L + 1))
+        if n:
+            ids[b, L - n:] = rng.integers(1, V, size=n)
+    ans = rng.integers(1, V, size=B).astype(np.int64)
+    model = build_model(cfg, params)
+    model.train()
+    model.set_seed(1234)
+    loss = model.calculate_loss(torch.from_numpy(ids).cuda(), torch.from_numpy(ans).cuda(), None, None, None)
+    loss.backward()
+    drop = O.DropoutSpec(train=True, seed=1234, step=1)
+    oloss, ologits, G, outs = O.loss_and_grads(params, cfg, ids, ans, drop)
+    plan = model._plan(B)
+    from bsarec_amd import _lib as Lb
+    got = [plan.view(Lb.BUF_LAYER_OUT, l, (B, L, cfg.hidden_size)).cpu().numpy() for l in range(cfg.num_hidden_layers + 1)]
+    for i, (g, r) in enumerate(zip(got, outs)):
+        assert np.abs(g - r).max() <= 1e-3, (i, np.abs(g - r).max())
+        assert rel_l2(g, r) <= 2e-5, (i, rel_l2(g, r))
+    assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
+    check_grads(model, G, tol=2e-4)
+
+
+def test_eval_mode_ignores_dropout_and_is_deterministic():
+    cfg, params, _, _, z = load_e2e("A_d64_L50_h2")
+    cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob = 0.5, 0.5
+    model = build_model(cfg, params)
+    model.eval()
+    ids = torch.from_numpy(z["ids"]).cuda()
+    a = model.predict(ids, None)
+    b = model.predict(ids, None)
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy()[z["ids"] > 0], z[f"out/{cfg.num_hidden_layers}"][z["ids"] > 0], atol=2e-5)
+    model.train()
+    c = model.forward(ids)
+    d = model.forward(ids)
+    assert not torch.equal(c, d)                         # new step -> new masks
