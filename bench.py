@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Training-throughput bench of the HIP BSARec path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = Trainer.iteration's per-batch body (src/trainers.py:100-107) on one batch of the
+ML-1M-shaped synthetic workload (C1 of SURVEY 8d: V=3417, L=50, d=64, 2 layers, 2 heads, c=3,
+alpha=0.9, dropout 0.5, Adam lr 1e-3, B=256 sequences per GPU): device-side batch gather,
+forward, full-catalogue CE, backward, (gradient all-reduce for N > 1), fused Adam.  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+
+
+def model_args(a):
+    return argparse.Namespace(
+        item_size=a.item_size, hidden_size=a.hidden, max_seq_length=a.seq_len, batch_size=a.batch,
+        hidden_dropout_prob=0.5, attention_probs_dropout_prob=0.5, num_hidden_layers=a.layers,
+        num_attention_heads=a.heads, hidden_act="gelu", initializer_range=0.02, c=3, alpha=0.9, seed=42,
+        lr=1e-3, adam_beta1=0.9, adam_beta2=0.999, weight_decay=0.0, no_cuda=False, log_freq=1)
+
+
+def train_flops_per_seq(a, cb=2):
+    d, L, N, V = a.hidden, a.seq_len, a.layers, a.item_size
+    return 3.0 * (N * L * (24 * d * d + 4 * L * d + 8 * cb * d) + 2 * d * V)
+
+
+def cpu_baseline(a, budget_s=12.0):
+    """The CPU oracle (numpy restatement, validated against the imported reference) timed on this
+    box's host cores on a bounded sample of the same workload: whole training steps at C1 shape."""
+    from oracle import bsarec_oracle as O
+    cfg = O.Config(item_size=a.item_size, hidden_size=a.hidden, max_seq_length=a.seq_len, num_hidden_layers=a.layers,
+                   num_attention_heads=a.heads, c=3, alpha=0.9)
+    P = O.init_params(cfg, 0)
+    rng = np.random.default_rng(0)
+    ids = rng.integers(1, a.item_size, size=(a.batch, a.seq_len))
+    for b in range(a.batch):
+        ids[b, :rng.integers(0, a.seq_len)] = 0
+    ans = rng.integers(1, a.item_size, size=a.batch)
+    st = O.AdamState()
+    _, _, G, _ = O.loss_and_grads(P, cfg, ids, ans, O.DropoutSpec(True, 1, 1))      # warm-up
+    O.adam_step(P, G, st)
+    n, t0 = 0, time.time()
+    while time.time() - t0 < budget_s and n < 64:
+        _, _, G, _ = O.loss_and_grads(P, cfg, ids, ans, O.DropoutSpec(True, 1, n + 2))
+        O.adam_step(P, G, st)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n * a.batch / dt, 1), "unit": "sequences/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} full training steps (fwd+bwd+Adam, dropout on) of B={a.batch} at the C1 shape, "
+                      f"numpy oracle with BLAS threads on all host cores, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="sequences per GPU per step (reference default 256)")
+    ap.add_argument("--item_size", type=int, default=3417)
+    ap.add_argument("--seq_len", type=int, default=50)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--heads", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        pg = torch.distributed.group.WORLD
+
+    from bsarec_amd import BSARecModel, _lib as Lb
+    from bsarec_amd import data as D
+    from bsarec_amd.trainer import Trainer
+
+    margs = model_args(a)
+    torch.manual_seed(42)                               # identical replicas on every rank
+    model = BSARecModel(margs).to(dev)
+    model.set_seed(42, rank)
+    # ML-1M-shaped synthetic interactions -> device-resident sample table (identical on every rank)
+    seqs = D.synth_ml1m_like(seed=42, n_items=a.item_size - 1)
+    users, inputs, answers = D.train_table(seqs, a.seq_len)
+    batches = D.DeviceBatches(users, inputs, answers, a.batch, dev, shuffle=True, seed=42, rank=rank, world=world)
+    trainer = Trainer(model, batches, None, None, margs, None, use_graph=not a.no_graph, process_group=pg)
+    use_graph = trainer.use_graph
+
+    def batch_stream():
+        while True:
+            for b in batches:
+                if b[1].shape[0] == a.batch:           # fixed-size steps only inside the timed region
+                    yield b
+
+    stream = batch_stream()
+
+    def one_step():
+        _, ids, ans, _, _ = next(stream)
+        if use_graph:
+            first = a.batch not in trainer._graphs
+            loss = trainer._step_graph(ids, ans)
+            if first:
+                loss = trainer._step_graph(ids, ans)
+            return loss
+        return trainer._step_eager(ids, ans)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    model.train()
+    for _ in range(max(a.warmup, 1)):
+        loss = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+    assert np.isfinite(final_loss), "training diverged"
+
+    out = {
+        "metric": "train sequences/sec, ML-1M L=50 d=64 2-layer", "value": round(a.batch * world * a.steps / dt, 1),
+        "unit": "sequences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C1: ML-1M-shaped synthetic (6040 users, V={a.item_size}), L={a.seq_len} d={a.hidden} "
+                               f"{a.layers} BSARec layers, {a.heads} heads, c=3 alpha=0.9 dropout=0.5, Adam lr=1e-3; "
+                               "fwd + full-catalogue CE + bwd + Adam per step",
+                   "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq_len,
+                   "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
+                   "final_loss": round(final_loss, 4)},
+    }
+    flops_seq = train_flops_per_seq(a)
+    out["step_mfma_frac"] = round(flops_seq * a.batch * world * a.steps / dt / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 5)
+
+    if rank == 0 and world == 1 and not a.no_roofline:
+        # dominant contraction (FFN dense_1: [B*L, d] x [d, 4d], 2*T*d*4d FLOP per launch), timed with
+        # hipEvents on its launch stream inside real (eager) training steps
+        lib = Lb.load()
+        lib.bsarec_profile_select(Lb.K_FFN1)
+        nprof = 20
+        for _ in range(nprof):
+            _, ids, ans, _, _ = next(stream)
+            trainer._step_eager(ids, ans)
+        torch.cuda.synchronize()
+        import ctypes as C
+        ms, n = C.c_double(), C.c_int()
+        lib.bsarec_profile_read(C.byref(ms), C.byref(n))
+        lib.bsarec_profile_select(Lb.K_NONE)
+        T = a.batch * a.seq_len
+        fl = 2.0 * T * a.hidden * 4 * a.hidden
+        avg_s = ms.value * 1e-3 / max(n.value, 1)
+        ach = fl / avg_s / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)",
+                           "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                           "launches_timed": n.value, "avg_us": round(avg_s * 1e6, 3),
+                           "flops_per_launch": fl}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

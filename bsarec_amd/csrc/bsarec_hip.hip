@@ -12,6 +12,11 @@
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define RET(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
 
+// Dry run: walk the launch sequence, set per-kernel attributes (large dynamic LDS), launch nothing.
+// bsarec_plan_create does one dry pass so that the first real pass may already be under graph capture.
+static thread_local bool g_dry = false;
+#define LAUNCH(...) do { if (!g_dry) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long rup(long a, long b) { return (a + b - 1) / b * b; }
 
@@ -62,6 +67,7 @@ static int launch_gemm(const GemmP& P, const XformP& X, const Epi& epi, float* b
     }
     if (P.M <= 0 || P.N <= 0) return 0;
     dim3 grid(cdiv(P.M, BM), cdiv(P.N, BN), nbatch * P.nprob * P.nsplit);
+    if (g_dry) return 0;
     ProfScope prof(kclass, s);
     hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), smem, s, P, X, epi, bgrad);
     return (int)hipGetLastError();
@@ -251,6 +257,14 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
                                   (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);   // jobs vector is host-temporary
     if (e != hipSuccess) { delete p; return (int)e; }
+    // dry pass: sets every kernel's dynamic-LDS attribute for this shape without launching anything
+    g_dry = true;
+    int rc = bsarec_forward(p, reinterpret_cast<const int64_t*>(p->ws), 1, stream);
+    if (rc == 0) rc = bsarec_loss(p, reinterpret_cast<const int64_t*>(p->ws), stream);
+    if (rc == 0 && p->G.item_emb) rc = bsarec_backward(p, stream);
+    g_dry = false;
+    p->train = false;
+    if (rc != 0) { delete p; return rc; }
     *out = p;
     return 0;
 }
@@ -319,7 +333,7 @@ static int launch_freq_fwd(const float* X, const float* sb, const float* g, cons
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = smem;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, sb, g, be, eps, drop, tw, L, d, cb, dsp, xhat, rstd);
+    LAUNCH(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, sb, g, be, eps, drop, tw, L, d, cb, dsp, xhat, rstd);
     return (int)hipGetLastError();
 }
 
@@ -333,18 +347,18 @@ static int launch_freq_bwd(const float* X, const float* dF, const float* dXin, c
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = smem;
     }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, dF, dXin, sb, tw, L, d, cb, dX, pbeta);
+    LAUNCH(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, dF, dXin, sb, tw, L, d, cb, dX, pbeta);
     return (int)hipGetLastError();
 }
 
 static int launch_reduce(const ReduceJob* jobs, int njobs, long maxlen, hipStream_t s) {
-    hipLaunchKernelGGL(multi_reduce_kernel, dim3(cdiv(maxlen, ROW_THREADS), njobs), dim3(ROW_THREADS), 0, s, jobs);
+    LAUNCH(multi_reduce_kernel, dim3(cdiv(maxlen, ROW_THREADS), njobs), dim3(ROW_THREADS), 0, s, jobs);
     return (int)hipGetLastError();
 }
 
 extern "C" int bsarec_step_begin(bsarec_plan_t* p, void* stream) {
     if (!p) return -10;
-    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state);
+    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state);
     return (int)hipGetLastError();
 }
 
@@ -362,7 +376,7 @@ extern "C" int bsarec_forward(bsarec_plan_t* p, const int64_t* ids, int train, v
 
     DISPATCH_LPR(d, {
         constexpr int RPB = ROW_THREADS / LPR;
-        hipLaunchKernelGGL(embed_fwd_kernel<LPR>, dim3(cdiv(T, RPB)), dim3(ROW_THREADS), 0, s, ids, p->P.item_emb,
+        LAUNCH(embed_fwd_kernel<LPR>, dim3(cdiv(T, RPB)), dim3(ROW_THREADS), 0, s, ids, p->P.item_emb,
                            p->P.pos_emb, p->P.ln_w, p->P.ln_b, c.ln_eps, make_drop(*p, c.p_hidden, 0, tr), T, L, d,
                            c.item_size, p->X[0], p->xhat0, p->rstd0, p->ids32);
         HIPCHK(hipGetLastError());
@@ -461,10 +475,10 @@ extern "C" int bsarec_loss(bsarec_plan_t* p, const int64_t* answers, void* strea
     hipStream_t s = (hipStream_t)stream;
     RET(bsarec_logits(p, stream));
     const bsarec_config_t& c = p->cfg;
-    hipLaunchKernelGGL(ce_rows_kernel, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, c.item_size, p->Vp,
+    LAUNCH(ce_rows_kernel, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, c.item_size, p->Vp,
                        1.0f / (float)c.batch, p->dlogits, p->loss_rows);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->loss_rows, c.batch, p->loss);
+    LAUNCH(loss_mean_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->loss_rows, c.batch, p->loss);
     return (int)hipGetLastError();
 }
 
@@ -500,7 +514,7 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
     }
     float* dY = (N & 1) ? p->dXb : p->dXa;       // gradient w.r.t. X[l+1]; ping-pong so that dX[0] lands in dXa
-    hipLaunchKernelGGL(dlast_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, p->dlast_slab,
+    LAUNCH(dlast_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, p->dlast_slab,
                        p->vsplit, (long)B * d, T, L, d, dY);
     HIPCHK(hipGetLastError());
 
@@ -515,7 +529,7 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
             a.xhat = b.xhat_ff; a.rstd = b.rstd_ff; a.gamma = w.ffn_ln_w; a.in_scale = 1.f;
             a.drop = make_drop(*p, c.p_hidden, 4 + 4 * l, tr); a.dT = p->dT;
             a.pgamma = p->part_ln + 0L * nb * d; a.pbeta = p->part_ln + 1L * nb * d;
-            DISPATCH_LPR(d, hipLaunchKernelGGL((ln_bwd_kernel<LPR, 0>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, 64));
+            DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 0>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, 64));
             HIPCHK(hipGetLastError());
         }
         {   // dU = (dT2 . W2) * gelu'(U)
@@ -556,7 +570,7 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
             f.xhat = b.xhat_f; f.rstd = b.rstd_f; f.gamma = w.filter_ln_w; f.in_scale = c.alpha;
             f.drop = make_drop(*p, c.p_hidden, 1 + 4 * l, tr); f.dT = p->dF;
             f.pgamma = p->part_ln + 4L * nb * d; f.pbeta = p->part_ln + 5L * nb * d;
-            DISPATCH_LPR(d, hipLaunchKernelGGL((ln_bwd_kernel<LPR, 1>), dim3(nb), dim3(ROW_THREADS), 0, s, p->dH, a, f, p->dXacc, T, d, 64));
+            DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 1>), dim3(nb), dim3(ROW_THREADS), 0, s, p->dH, a, f, p->dXacc, T, d, 64));
             HIPCHK(hipGetLastError());
         }
         // ---- attention backward
@@ -637,12 +651,12 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         a.xhat = p->xhat0; a.rstd = p->rstd0; a.gamma = p->P.ln_w; a.in_scale = 1.f;
         a.drop = make_drop(*p, c.p_hidden, 0, tr); a.dT = nullptr;
         a.pgamma = p->part_ln + 0L * nb * d; a.pbeta = p->part_ln + 1L * nb * d;
-        DISPATCH_LPR(d, hipLaunchKernelGGL((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, 64));
+        DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, 64));
         HIPCHK(hipGetLastError());
         DISPATCH_LPR(d, {
             constexpr int RPP = ROW_THREADS / LPR;
             const int sb = cdiv(T, RPP);
-            hipLaunchKernelGGL(embed_bwd_kernel<LPR>, dim3(sb + L), dim3(ROW_THREADS), 0, s, p->dz, p->ids32, B, L, d,
+            LAUNCH(embed_bwd_kernel<LPR>, dim3(sb + L), dim3(ROW_THREADS), 0, s, p->dz, p->ids32, B, L, d,
                                p->G.item_emb, p->G.pos_emb, sb);
             HIPCHK(hipGetLastError());
         });
@@ -658,12 +672,12 @@ extern "C" int bsarec_adam_step(float* params, const float* grads, float* m, flo
                                 float b1, float b2, float eps, float wd, float gscale, void* stream) {
     if (!params || !grads || !m || !v || !state || n <= 0 || (n & 3)) return -10;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, (uint64_t*)state, (double)lr, (double)b1, (double)b2);
+    LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, s, (uint64_t*)state, (double)lr, (double)b1, (double)b2);
     HIPCHK(hipGetLastError());
     const long n4 = n / 4;
     int blocks = cdiv(n4, ROW_THREADS);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, params, grads, m, v, n4, (const uint64_t*)state,
+    LAUNCH(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, params, grads, m, v, n4, (const uint64_t*)state,
                        b1, b2, eps, wd, gscale);
     return (int)hipGetLastError();
 }
@@ -717,7 +731,7 @@ extern "C" int bsarec_freq_layer_bwd(const float* x, const float* dy, const floa
     LnBranch a; memset(&a, 0, sizeof(a));
     a.xhat = xhat; a.rstd = rstd; a.gamma = ln_w; a.in_scale = 1.f; a.drop = standalone_drop(p_drop, state, site);
     a.dT = dF; a.pgamma = pg; a.pbeta = pb;
-    DISPATCH_LPR(d, hipLaunchKernelGGL((ln_bwd_kernel<LPR, 0>), dim3(nb), dim3(ROW_THREADS), 0, s, dy, a, a, dz, T, d, 64));
+    DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 0>), dim3(nb), dim3(ROW_THREADS), 0, s, dy, a, a, dz, T, d, 64));
     HIPCHK(hipGetLastError());
     // y = LN(Drop(f(x)) + x): the residual contributes dz directly
     DISPATCH_LPR(d, RET(launch_freq_bwd<LPR>(x, dF, dz, sqrt_beta, twiddle, B, L, d, cb, dx, pbeta, s)));

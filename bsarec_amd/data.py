@@ -1,0 +1,137 @@
+"""Input side of the hot path: the reference's dataset format restated as device-resident tables.
+
+The reference feeds the model through a Python ``Dataset`` + ``DataLoader`` (src/dataset.py:9-117,
+207-221) that tops out near 44 k samples/s; here the same samples are tensorised once and live in
+HBM, and a batch is an index gather on the device.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def read_user_seqs(path: str) -> Tuple[List[List[int]], int, int]:
+    """``user item item ...`` per line (src/dataset.py:184-197) -> (sequences, max_item, num_users)."""
+    seqs: List[List[int]] = []
+    max_item = 0
+    with open(path) as fh:
+        for line in fh:
+            parts = line.strip().split(" ")
+            items = [int(x) for x in parts[1:]]
+            seqs.append(items)
+            if items:
+                max_item = max(max_item, max(items))
+    return seqs, max_item, len(seqs)
+
+
+def synth_ml1m_like(seed: int = 42, n_users: int = 6040, n_items: int = 3416) -> List[List[int]]:
+    """ML-1M-shaped synthetic interactions (the real ML-1M.txt is absent from the reference mount,
+    SURVEY 8d C1): lengths max(20, lognormal(4.6, 0.9)) clipped to 2314, items Zipf(1.0) over a
+    fixed random permutation of 1..n_items."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.maximum(20, np.rint(rng.lognormal(4.6, 0.9, size=n_users))), 20, 2314).astype(np.int64)
+    w = 1.0 / np.arange(1, n_items + 1)
+    cdf = np.cumsum(w / w.sum())
+    perm = rng.permutation(n_items) + 1
+    out = []
+    for n in lens:
+        out.append(perm[np.minimum(np.searchsorted(cdf, rng.random(n)), n_items - 1)].tolist())
+    return out
+
+
+def write_user_seqs(path: str, seqs: List[List[int]]) -> None:
+    with open(path, "w") as fh:
+        for u, s in enumerate(seqs, 1):
+            fh.write(str(u) + " " + " ".join(map(str, s)) + "\n")
+
+
+def train_table(user_seqs: List[List[int]], L: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """All training prefixes (src/dataset.py:18-23,61-72): per user t = s[-(L+2):-2]; sample i is
+    (t[:i] left-padded to L, t[i]); i = 0 is an all-padding input.  Returns (user, inputs, answers)."""
+    users, ins, ans = [], [], []
+    for u, s in enumerate(user_seqs):
+        t = np.asarray(s[-(L + 2):-2], dtype=np.int64)
+        n = len(t)
+        if n == 0:
+            continue
+        padded = np.concatenate([np.zeros(L, dtype=np.int64), t])
+        win = np.lib.stride_tricks.sliding_window_view(padded, L)[:n]       # window i = L items before t[i]
+        ins.append(win)
+        ans.append(t)
+        users.append(np.full(n, u, dtype=np.int64))
+    return np.concatenate(users), np.concatenate(ins), np.concatenate(ans)
+
+
+def eval_table(user_seqs: List[List[int]], L: int, split: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """valid: (s[:-2], s[-2]); test: (s[:-1], s[-1]) (src/dataset.py:24-28,69-81)."""
+    cut = 2 if split == "valid" else 1
+    n = len(user_seqs)
+    ins = np.zeros((n, L), dtype=np.int64)
+    ans = np.zeros(n, dtype=np.int64)
+    for u, s in enumerate(user_seqs):
+        h = s[:-cut][-L:]
+        if h:
+            ins[u, L - len(h):] = h
+        ans[u] = s[-cut]
+    return np.arange(n, dtype=np.int64), ins, ans
+
+
+def seen_csr(user_seqs: List[List[int]], split: str) -> Tuple[np.ndarray, np.ndarray]:
+    """Items masked at evaluation: s[:-2] for valid, s[:-1] for test (src/dataset.py:126-160),
+    as CSR (indptr, cols) with duplicates removed."""
+    cut = 2 if split == "valid" else 1
+    indptr = [0]
+    cols = []
+    for s in user_seqs:
+        u = np.unique(np.asarray(s[:-cut], dtype=np.int64))
+        cols.append(u)
+        indptr.append(indptr[-1] + len(u))
+    return np.asarray(indptr, dtype=np.int64), (np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64))
+
+
+class DeviceBatches:
+    """Device-resident replacement of the reference's train DataLoader (RandomSampler, batch_size,
+    no drop_last; src/dataset.py:209-211).  Iterating yields the reference's 5-tuples
+    (user_ids, input_ids, answers, neg_answer, same_target) with tensors already on the GPU.
+
+    Data parallel: every rank draws the same per-epoch permutation (seed + epoch) and takes the
+    rank-th slice of each global batch of world*batch_size samples."""
+
+    def __init__(self, users, inputs, answers, batch_size: int, device, shuffle: bool = True, seed: int = 42,
+                 rank: int = 0, world: int = 1, drop_last: bool = False):
+        self.users = torch.as_tensor(users, dtype=torch.int64, device=device)
+        self.inputs = torch.as_tensor(np.ascontiguousarray(inputs), dtype=torch.int64, device=device)
+        self.answers = torch.as_tensor(answers, dtype=torch.int64, device=device)
+        self.batch_size, self.shuffle, self.seed = batch_size, shuffle, seed
+        # data parallel: a short last global batch would give ranks unequal (or empty) shards and a
+        # mis-weighted gradient mean, so it is dropped on every rank; single-GPU keeps it, as the reference does
+        self.rank, self.world, self.drop_last = rank, world, (drop_last or world > 1)
+        self.epoch = 0
+        self.device = device
+        self._empty = torch.zeros((0,), dtype=torch.int64, device=device)
+
+    def __len__(self):
+        g = self.batch_size * self.world
+        n = self.answers.shape[0]
+        return n // g if self.drop_last else (n + g - 1) // g
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __iter__(self):
+        n = self.answers.shape[0]
+        if self.shuffle:
+            gen = torch.Generator(device="cpu")
+            gen.manual_seed(self.seed + self.epoch)
+            perm = torch.randperm(n, generator=gen).to(self.device)
+        else:
+            perm = torch.arange(n, device=self.device)
+        g = self.batch_size * self.world
+        for i in range(len(self)):
+            idx = perm[i * g:(i + 1) * g]
+            if self.world > 1:
+                idx = idx[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
+            yield (self.users[idx], self.inputs[idx], self.answers[idx], self._empty, self._empty.view(0))
+        self.epoch += 1

@@ -1,0 +1,189 @@
+"""Host-side mirror of the reference ``Trainer`` (src/trainers.py:8-158) over the HIP path.
+
+Same constructor and methods (``train / valid / test / iteration / save / load / predict_full /
+get_full_sort_score``); the per-batch body of ``iteration(train=True)`` is ONE C call
+(``bsarec_train_step``: forward + loss + backward + fused Adam), optionally replayed from a captured
+hipGraph, the epoch loss is accumulated on the device (no per-step ``loss.item()`` sync), and the
+evaluation branch scores, masks seen items and takes the top-20 on the GPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .model import BSARecModel
+
+
+class _NullLogger:
+    def info(self, *a, **k):
+        pass
+
+
+def recall_at_k(hit: torch.Tensor, k: int) -> float:
+    """src/metrics.py:3-13 for single-target lists: hit is bool[n, 20]."""
+    return float(hit[:, :k].any(1).double().mean().item())
+
+
+def ndcg_at_k(hit: torch.Tensor, k: int) -> float:
+    """src/metrics.py:15-31: one relevant item -> idcg = 1, dcg = 1/log2(rank + 2)."""
+    w = 1.0 / torch.log2(torch.arange(k, device=hit.device, dtype=torch.float64) + 2.0)
+    return float((hit[:, :k].double() * w).sum(1).mean().item())
+
+
+class Trainer:
+    def __init__(self, model: BSARecModel, train_dataloader, eval_dataloader, test_dataloader, args, logger=None,
+                 use_graph: bool = True, process_group=None):
+        self.args = args
+        self.logger = logger or _NullLogger()
+        if not torch.cuda.is_available() or getattr(args, "no_cuda", False):
+            raise RuntimeError("bsarec_amd.Trainer needs an MI355X: there is no CPU training path "
+                               "(the CPU restatement under oracle/ is test infrastructure)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.model = model.to(self.device) if model._arena.device != self.device else model
+        self.train_dataloader, self.eval_dataloader, self.test_dataloader = train_dataloader, eval_dataloader, test_dataloader
+        self.model.configure_adam(lr=args.lr, betas=(args.adam_beta1, args.adam_beta2),
+                                  weight_decay=args.weight_decay)           # src/trainers.py:27-28
+        self.logger.info(f"Total Parameters: {sum(p.nelement() for p in self.model.parameters())}")
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.use_graph = use_graph and self.world == 1
+        self._graphs = {}
+        self._seen_cache = {}
+
+    # ---- reference API ---------------------------------------------------------------------------
+    def train(self, epoch):
+        return self.iteration(epoch, self.train_dataloader, train=True)
+
+    def valid(self, epoch):
+        self.args.train_matrix = self.args.valid_rating_matrix
+        return self.iteration(epoch, self.eval_dataloader, train=False)
+
+    def test(self, epoch):
+        self.args.train_matrix = self.args.test_rating_matrix
+        return self.iteration(epoch, self.test_dataloader, train=False)
+
+    def save(self, file_name):
+        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, file_name)
+
+    def load(self, file_name):
+        sd = torch.load(file_name, map_location="cpu", weights_only=True)
+        self.model.load_state_dict(sd)
+
+    def predict_full(self, seq_out):
+        """src/trainers.py:62-68 (kept for API parity; evaluation uses model.full_logits)."""
+        return torch.matmul(seq_out, self.model.item_embeddings.weight.transpose(0, 1))
+
+    def get_full_sort_score(self, epoch, answers, pred_list):
+        """src/trainers.py:70-83: answers int[n], pred_list int[n, 20] (device tensors or numpy)."""
+        ans = torch.as_tensor(answers, device=self.device).view(-1, 1)
+        pred = torch.as_tensor(pred_list, device=self.device)
+        hit = pred == ans
+        recall = [recall_at_k(hit, k) for k in (5, 10, 15, 20)]
+        ndcg = [ndcg_at_k(hit, k) for k in (5, 10, 15, 20)]
+        post_fix = {
+            "Epoch": epoch,
+            "HR@5": '{:.4f}'.format(recall[0]), "NDCG@5": '{:.4f}'.format(ndcg[0]),
+            "HR@10": '{:.4f}'.format(recall[1]), "NDCG@10": '{:.4f}'.format(ndcg[1]),
+            "HR@20": '{:.4f}'.format(recall[3]), "NDCG@20": '{:.4f}'.format(ndcg[3]),
+        }
+        self.logger.info(post_fix)
+        return [recall[0], ndcg[0], recall[1], ndcg[1], recall[3], ndcg[3]], str(post_fix)
+
+    # ---- one optimisation step --------------------------------------------------------------------
+    def _step_eager(self, ids, ans):
+        m = self.model
+        if self.world == 1:
+            return m.train_step(ids, ans)
+        # data parallel: local forward/backward, ONE summing all-reduce of the flat gradient arena
+        # (RCCL over xGMI), Adam on the mean; every rank holds identical replicas
+        plan = m._run_forward(ids, train=True, new_step=True)
+        m._run_loss(plan, ans)
+        m._run_backward(plan)
+        torch.distributed.all_reduce(m._garena, group=self.pg)
+        m.adam_step(grad_scale=1.0 / self.world)
+        from . import _lib as L
+        return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
+    def _step_graph(self, ids, ans):
+        """Replay the whole step from a hipGraph captured per batch size (static id/answer buffers)."""
+        B = ids.shape[0]
+        g = self._graphs.get(B)
+        if g is None:
+            sid, sans = ids.clone(), ans.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.model._plan(B)                         # plan creation synchronises: do it before capture
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = self.model.train_step(sid, sans)
+            g = self._graphs[B] = (graph, sid, sans, loss)
+            return loss                                     # capture does not run: fall through to a replay
+        graph, sid, sans, loss = g
+        sid.copy_(ids)
+        sans.copy_(ans)
+        graph.replay()
+        return loss
+
+    def iteration(self, epoch, dataloader, train=True):
+        if train:
+            self.model.train()
+            loss_sum = torch.zeros((), dtype=torch.float32, device=self.device)
+            nb = 0
+            for batch in dataloader:
+                batch = tuple(t.to(self.device, non_blocking=True) for t in batch)
+                _, input_ids, answers, _, _ = batch
+                if self.use_graph:
+                    B = input_ids.shape[0]
+                    first = B not in self._graphs
+                    loss = self._step_graph(input_ids, answers)
+                    if first:
+                        loss = self._step_graph(input_ids, answers)
+                else:
+                    loss = self._step_eager(input_ids, answers)
+                loss_sum += loss
+                nb += 1
+            rec = loss_sum.item() / max(nb, 1)
+            if self.world > 1:
+                t = torch.tensor([rec], device=self.device)
+                torch.distributed.all_reduce(t, group=self.pg)
+                rec = t.item() / self.world
+            post_fix = {"epoch": epoch, "rec_loss": '{:.4f}'.format(rec)}
+            if (epoch + 1) % getattr(self.args, "log_freq", 1) == 0:
+                self.logger.info(str(post_fix))
+            return post_fix
+        # ---- evaluation (src/trainers.py:118-158), all on the device
+        self.model.eval()
+        preds, answers_all = [], []
+        for batch in dataloader:
+            batch = tuple(t.to(self.device, non_blocking=True) for t in batch)
+            user_ids, input_ids, answers, _, _ = batch
+            scores = self.model.full_logits(input_ids).clone()
+            rows, cols = self._seen(user_ids)
+            scores[rows, cols] = 0                              # seen items := 0 (not -inf), trainers.py:134
+            preds.append(torch.topk(scores, 20, dim=1).indices)
+            answers_all.append(answers)
+        return self.get_full_sort_score(epoch, torch.cat(answers_all), torch.cat(preds))
+
+    def _seen(self, user_ids):
+        """(row-in-batch, item) pairs of already-seen items from args.train_matrix (scipy CSR, as the
+        reference builds it in src/dataset.py:126-168) -- uploaded once per matrix."""
+        mat = self.args.train_matrix
+        key = id(mat)
+        if key not in self._seen_cache:
+            csr = mat.tocsr()
+            csr.sum_duplicates()
+            self._seen_cache = {key: (torch.as_tensor(csr.indptr.astype(np.int64), device=self.device),
+                                      torch.as_tensor(csr.indices.astype(np.int64), device=self.device))}
+        indptr, indices = self._seen_cache[key]
+        start, end = indptr[user_ids], indptr[user_ids + 1]
+        counts = end - start
+        rows = torch.repeat_interleave(torch.arange(user_ids.shape[0], device=self.device), counts)
+        offs = torch.arange(int(counts.sum().item()), device=self.device) - torch.repeat_interleave(
+            torch.cumsum(counts, 0) - counts, counts)
+        cols = indices[torch.repeat_interleave(start, counts) + offs]
+        return rows, cols
