@@ -11,6 +11,8 @@ from typing import List, Optional, Tuple
 import numpy as np
 import torch
 
+from .dp import shard_of_global_batch
+
 
 def read_user_seqs(path: str) -> Tuple[List[List[int]], int, int]:
     """``user item item ...`` per line (src/dataset.py:184-197) -> (sequences, max_item, num_users)."""
@@ -132,6 +134,6 @@ class DeviceBatches:
         for i in range(len(self)):
             idx = perm[i * g:(i + 1) * g]
             if self.world > 1:
-                idx = idx[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
+                idx = shard_of_global_batch(idx, self.batch_size, self.rank, self.world)
             yield (self.users[idx], self.inputs[idx], self.answers[idx], self._empty, self._empty.view(0))
         self.epoch += 1

@@ -14,6 +14,7 @@ from typing import Optional
 import numpy as np
 import torch
 
+from .dp import allreduce_sum_
 from .model import BSARecModel
 
 
@@ -102,8 +103,8 @@ class Trainer:
         plan = m._run_forward(ids, train=True, new_step=True)
         m._run_loss(plan, ans)
         m._run_backward(plan)
-        torch.distributed.all_reduce(m._garena, group=self.pg)
-        m.adam_step(grad_scale=1.0 / self.world)
+        scale = allreduce_sum_(m._garena, self.pg)
+        m.adam_step(grad_scale=scale)
         from . import _lib as L
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 

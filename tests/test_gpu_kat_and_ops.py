@@ -1,0 +1,175 @@
+"""GPU tests beyond the e2e goldens: the reference's shipped checkpoints as known-answer tests through
+the HIP eval path, per-op FrequencyLayer vectors, a full-size C1 step against the oracle, the Trainer
+loop (graph replay == eager), and size-independent properties at the bench's full size."""
+import argparse
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_e2e, rel_l2
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def ns(**kw):
+    a = argparse.Namespace(item_size=97, hidden_size=64, max_seq_length=50, batch_size=256, hidden_dropout_prob=0.5,
+                           attention_probs_dropout_prob=0.5, num_hidden_layers=2, num_attention_heads=2,
+                           hidden_act="gelu", initializer_range=0.02, c=3, alpha=0.9, seed=42, lr=1e-3,
+                           adam_beta1=0.9, adam_beta2=0.999, weight_decay=0.0, no_cuda=False, log_freq=1)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def load_kat(name):
+    z = np.load(os.path.join(GOLDEN, f"kat_{name}.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    off, items = z["seq_offsets"], z["seq_items"]
+    seqs = [items[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+    return z, cfg, seqs
+
+
+@pytest.mark.parametrize("name", ["LastFM", "Beauty"])
+def test_shipped_checkpoint_known_answers(name):
+    """src/output/BSARec_{name}_best.pt through BSARecModel + Trainer.test on the GPU reproduces the
+    reference's six logged test metrics, its top-10 lists and its logits."""
+    import scipy.sparse as sp
+    from bsarec_amd import BSARecModel, data as D
+    from bsarec_amd.trainer import Trainer
+    z, cfg, seqs = load_kat(name)
+    a = ns(item_size=cfg["item_size"], num_attention_heads=cfg["num_attention_heads"], c=cfg["c"], alpha=cfg["alpha"])
+    model = BSARecModel(a)
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p/")})
+    model = model.cuda()
+    users, ins, ans = D.eval_table(seqs, 50, "test")
+    test_dl = D.DeviceBatches(users, ins, ans, 256, "cuda", shuffle=False)
+    indptr, cols = D.seen_csr(seqs, "test")
+    a.test_rating_matrix = sp.csr_matrix((np.ones(len(cols)), cols, indptr), shape=(len(seqs), cfg["item_size"]))
+    a.valid_rating_matrix = a.test_rating_matrix
+    tr = Trainer(model, None, None, test_dl, a, None)
+    scores, info = tr.test(0)
+    np.testing.assert_allclose(scores, z["metrics"], rtol=0, atol=1e-12)
+    model.eval()
+    logits = model.full_logits(torch.from_numpy(ins[:8]).cuda()).cpu().numpy()
+    assert np.abs(logits - z["logits8"]).max() <= 1e-3 * np.abs(z["logits8"]).max()
+    assert np.abs(logits - z["logits8"]).max() <= 5e-5
+    # formatted like the reference log line
+    assert f"'HR@10': '{z['metrics'][2]:.4f}'" in info and f"'NDCG@10': '{z['metrics'][3]:.4f}'" in info
+
+
+def test_frequency_layer_op_vs_reference_vectors():
+    """Stand-alone FrequencyLayer entry points vs the imported reference for 8 (L, c) combos incl.
+    c >= L, odd L and L = 7."""
+    from bsarec_amd import _lib
+    from bsarec_amd.model import _twiddle
+    lib = _lib.load()
+    z = np.load(os.path.join(GOLDEN, "freq_ops.npz"))
+    st = torch.cuda.current_stream().cuda_stream
+    for i, (L, c) in enumerate(z["combos"]):
+        L, c = int(L), int(c)
+        cb = min(c // 2 + 1, L // 2 + 1)
+        t = {k: torch.from_numpy(z[f"{i}/{k}"]).cuda().contiguous() for k in ("x", "gy", "sqrt_beta", "ln_w", "ln_b")}
+        B, _, d = t["x"].shape
+        tw = _twiddle(L).cuda()
+        y, xhat = torch.empty_like(t["x"]), torch.empty_like(t["x"])
+        rstd = torch.empty(B * L, device="cuda")
+        rc = lib.bsarec_freq_layer_fwd(t["x"].data_ptr(), t["sqrt_beta"].data_ptr(), t["ln_w"].data_ptr(),
+                                       t["ln_b"].data_ptr(), tw.data_ptr(), B, L, d, cb, 1e-12, 0.0, None, 0,
+                                       y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), st)
+        assert rc == 0
+        np.testing.assert_allclose(y.cpu().numpy(), z[f"{i}/y"], atol=5e-6)
+        scratch = torch.empty(lib.bsarec_freq_layer_bwd_scratch_floats(B, L, d), device="cuda")
+        dx = torch.empty_like(t["x"])
+        dsb, dlw, dlb = (torch.empty(d, device="cuda") for _ in range(3))
+        rc = lib.bsarec_freq_layer_bwd(t["x"].data_ptr(), t["gy"].data_ptr(), xhat.data_ptr(), rstd.data_ptr(),
+                                       t["sqrt_beta"].data_ptr(), t["ln_w"].data_ptr(), tw.data_ptr(), B, L, d, cb, 0.0,
+                                       None, 0, scratch.data_ptr(), dx.data_ptr(), dsb.data_ptr(), dlw.data_ptr(),
+                                       dlb.data_ptr(), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(dx.cpu().numpy(), z[f"{i}/dx"], atol=3e-5)
+        np.testing.assert_allclose(dsb.cpu().numpy(), z[f"{i}/dsqrt_beta"].reshape(-1), rtol=2e-4, atol=3e-5)
+        np.testing.assert_allclose(dlw.cpu().numpy(), z[f"{i}/dln_w"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(dlb.cpu().numpy(), z[f"{i}/dln_b"], rtol=2e-4, atol=2e-5)
+
+
+def _c1_model_and_batch(B=256, V=3417, seed=0):
+    from bsarec_amd import BSARecModel, data as D
+    torch.manual_seed(seed)
+    model = BSARecModel(ns(item_size=V)).cuda()
+    seqs = D.synth_ml1m_like(seed=1, n_users=400, n_items=V - 1)
+    u, x, a = D.train_table(seqs, 50)
+    rng = np.random.default_rng(seed)
+    pick = rng.permutation(len(a))[:B]
+    return model, x[pick], a[pick]
+
+
+def test_full_size_c1_training_step_vs_oracle():
+    """The bench's own configuration (B=256, L=50, d=64, V=3417, 2 layers, dropout 0.5): loss, logits and
+    all gradients of one step against the oracle (same Philox masks)."""
+    from oracle import bsarec_oracle as O
+    model, ids, ans = _c1_model_and_batch()
+    model.train()
+    model.set_seed(7)
+    params = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    loss = model.calculate_loss(torch.from_numpy(ids).cuda(), torch.from_numpy(ans).cuda(), None, None, None)
+    loss.backward()
+    cfg = O.Config(item_size=3417)
+    oloss, ologits, G, _ = O.loss_and_grads(params, cfg, ids, ans, O.DropoutSpec(True, 7, 1))
+    assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
+    from bsarec_amd import _lib as Lb
+    logits = model._plan(256).view(Lb.BUF_LOGITS, 0, (256, 3420))[:, :3417].cpu().numpy()
+    assert np.abs(logits - ologits).max() <= 1e-3 * np.abs(ologits).max()
+    for k, g in model.grad_views().items():
+        if k.endswith("key.bias"):
+            assert g.abs().max().item() <= 1e-6
+            continue
+        assert rel_l2(g.cpu().numpy(), G[k]) <= 2e-4, (k, rel_l2(g.cpu().numpy(), G[k]))
+
+
+def test_full_size_properties_batch_equivariance_and_normalisation():
+    """Size-independent properties at the bench size: eval outputs are per-sequence (permuting the batch
+    permutes the outputs bit for bit), attention rows sum to 1, per-row dlogits sum to 0."""
+    from bsarec_amd import _lib as Lb
+    model, ids, ans = _c1_model_and_batch()
+    model.eval()
+    t = torch.from_numpy(ids).cuda()
+    perm = torch.randperm(256, device="cuda")
+    a = model.forward(t)
+    b = model.forward(t[perm])
+    assert torch.equal(a[perm], b)
+    plan = model._plan(256)
+    probs = plan.view(Lb.BUF_PROBS, 0, (256, 2, 50, 52))
+    np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, atol=2e-6)
+    assert probs[..., 50:].abs().max().item() == 0
+    x = a.cpu().numpy()                                    # LN output with gamma=1, beta=0 at init
+    np.testing.assert_allclose(x.mean(-1), 0, atol=1e-5)
+    np.testing.assert_allclose(x.var(-1), 1, atol=1e-3)
+
+
+def test_trainer_loop_graph_replay_equals_eager_and_learns():
+    """Trainer.iteration(train=True): hipGraph replay and eager launches give the same parameters bit
+    for bit (same Philox stream, deterministic reductions except the atomic scatter -> allow 1e-6), the
+    short last batch goes through its own plan, and the loss goes down."""
+    from bsarec_amd import BSARecModel, data as D
+    from bsarec_amd.trainer import Trainer
+    seqs = D.synth_ml1m_like(seed=3, n_users=60, n_items=300)
+    u, x, a = D.train_table(seqs, 50)
+    u, x, a = u[:1100], x[:1100], a[:1100]                  # 4 full batches + a short one
+    res = {}
+    for mode in ("graph", "eager"):
+        torch.manual_seed(1)
+        model = BSARecModel(ns(item_size=301)).cuda()
+        model.set_seed(5)
+        dl = D.DeviceBatches(u, x, a, 256, "cuda", shuffle=True, seed=11)
+        tr = Trainer(model, dl, None, None, ns(item_size=301), None, use_graph=(mode == "graph"))
+        losses = [float(tr.train(e)["rec_loss"]) for e in range(3)]
+        res[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+        assert losses[-1] < losses[0]
+    assert res["graph"][0] == res["eager"][0]
+    for k in res["graph"][1]:
+        np.testing.assert_allclose(res["graph"][1][k], res["eager"][1][k], atol=2e-6, err_msg=k)

@@ -1,0 +1,168 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/bsarec_hip.h, the host
+mirror keeps the reference's state_dict / constructor contract, the device-resident data tables
+reproduce the reference's sample construction, and the data-parallel scheme is exact (gloo, 2 ranks).
+No compute call is made here (there is no GPU)."""
+import argparse
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_e2e, rel_l2
+
+
+def args_for(**kw):
+    a = argparse.Namespace(item_size=97, hidden_size=64, max_seq_length=50, batch_size=256, hidden_dropout_prob=0.5,
+                           attention_probs_dropout_prob=0.5, num_hidden_layers=2, num_attention_heads=2,
+                           hidden_act="gelu", initializer_range=0.02, c=3, alpha=0.9)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_library_exports_every_header_symbol():
+    from bsarec_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "bsarec_hip.h")).read()
+    declared = set(re.findall(r"\b(bsarec_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.bsarec_abi_version() == _lib.ABI_VERSION
+
+
+def test_workspace_query_and_shape_limits():
+    import ctypes as C
+    from bsarec_amd import _lib
+    lib = _lib.load()
+    ok = _lib.Config(256, 50, 64, 2, 2, 3417, 2, 0.9, 1e-12, 0.5, 0.5)
+    assert lib.bsarec_workspace_bytes(C.byref(ok)) > 0
+    for bad in (dict(seq_len=300), dict(hidden=66), dict(hidden=512), dict(heads=3), dict(layers=0), dict(cutoff_bins=40)):
+        c = _lib.Config(256, 50, 64, 2, 2, 3417, 2, 0.9, 1e-12, 0.5, 0.5)
+        for k, v in bad.items():
+            setattr(c, k, v)
+        assert lib.bsarec_workspace_bytes(C.byref(c)) == 0, bad
+
+
+def test_model_state_dict_contract_and_arena():
+    from bsarec_amd import BSARecModel
+    cfg, params, _, _, _ = load_e2e("A_d64_L50_h2")
+    m = BSARecModel(args_for())
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(params.keys())                      # the reference's 42 keys, same order
+    assert all(tuple(sd[k].shape) == params[k].shape for k in sd)
+    assert sum(p.numel() for p in m.parameters()) == 97 * 64 + 103680    # 'Total Parameters' formula
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    # every parameter is a view of the one flat arena
+    for k, (o, n, shp) in m._slices.items():
+        assert m.state_dict()[k].data_ptr() == m._arena.data_ptr() + 4 * o
+        np.testing.assert_array_equal(m._arena[o:o + n].numpy().reshape(shp), params[k])
+    # init: N(0, 0.02) weights incl. padding row 0, zero biases, LN gamma 1, sqrt_beta ~ N(0,1)
+    m2 = BSARecModel(args_for(item_size=5000))
+    sd2 = m2.state_dict()
+    assert abs(sd2["item_embeddings.weight"].std().item() - 0.02) < 1e-3
+    assert sd2["item_embeddings.weight"][0].abs().sum() > 0
+    assert sd2["item_encoder.blocks.0.feed_forward.dense_1.bias"].abs().sum() == 0
+    assert torch.all(sd2["item_encoder.blocks.1.layer.attention_layer.LayerNorm.weight"] == 1)
+    assert 0.5 < sd2["item_encoder.blocks.0.layer.filter_layer.sqrt_beta"].std().item() < 1.5
+
+
+def test_model_errors_like_the_reference_and_has_no_cpu_path():
+    from bsarec_amd import BSARecModel
+    with pytest.raises(ValueError, match="not a multiple"):
+        BSARecModel(args_for(num_attention_heads=5))
+    m = BSARecModel(args_for())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.forward(torch.zeros(2, 50, dtype=torch.long))
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bsarec_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|import_module\(\s*['\"]oracle|#include\s+[<\"].*oracle", re.M)
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert not pat.search(open(os.path.join(dp, f)).read()), f
+
+
+def test_device_tables_match_reference_sample_construction():
+    from bsarec_amd import data as D
+    facts = json.load(open(os.path.join(GOLDEN, "data_facts.json")))
+    z = np.load(os.path.join(GOLDEN, "kat_LastFM.npz"))
+    off, items = z["seq_offsets"], z["seq_items"]
+    seqs = [items[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+    u, x, a = D.train_table(seqs, 50)
+    assert len(a) == facts["train"]["n"]
+    for split, tab in (("train", (u, x, a)), ("valid", D.eval_table(seqs, 50, "valid")), ("test", D.eval_table(seqs, 50, "test"))):
+        n = facts[split]["n"]
+        for j, s in list(enumerate(facts[split]["first"])) + [(n - 3 + j, s) for j, s in enumerate(facts[split]["last"])]:
+            assert (int(tab[0][j]), tab[1][j].tolist(), int(tab[2][j])) == (s["user"], s["input_ids"], s["answer"])
+    assert len(D.seen_csr(seqs, "valid")[1]) == facts["valid_nnz"]
+    assert len(D.seen_csr(seqs, "test")[1]) == facts["test_nnz"]
+    # text round trip in the reference's file format
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        D.write_user_seqs(os.path.join(td, "x.txt"), seqs[:50])
+        back, mx, nu = D.read_user_seqs(os.path.join(td, "x.txt"))
+        assert back == seqs[:50] and nu == 50 and mx == max(max(s) for s in seqs[:50])
+
+
+def test_device_batches_cover_every_sample_once_and_shard_disjointly():
+    from bsarec_amd import data as D
+    n, L = 1000, 8
+    users = np.arange(n)
+    inputs = np.arange(n * L).reshape(n, L)
+    answers = np.arange(n) + 7
+    b = D.DeviceBatches(users, inputs, answers, 64, "cpu", shuffle=True, seed=3)
+    seen = torch.cat([t[0] for t in b])
+    assert len(b) == 16 and sorted(seen.tolist()) == list(range(n))          # short last batch kept (world 1)
+    e0 = torch.cat([t[0] for t in b])
+    assert not torch.equal(seen, e0)                                         # new permutation next epoch
+    shards = [D.DeviceBatches(users, inputs, answers, 32, "cpu", seed=3, rank=r, world=2) for r in range(2)]
+    got = [list(s) for s in shards]
+    assert len(got[0]) == len(got[1]) == n // 64                              # short global batch dropped
+    for (u0, x0, a0, _, _), (u1, x1, a1, _, _) in zip(*got):
+        assert len(u0) == len(u1) == 32 and not set(u0.tolist()) & set(u1.tolist())
+        assert torch.equal(a0, u0 + 7) and torch.equal(x0[:, 0], u0 * L)
+
+
+def _dp_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    from bsarec_amd import dp
+    from oracle import bsarec_oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg, params, _, _, z = load_e2e("B_d16_L20_h1")
+    rng = np.random.default_rng(0)
+    Bl = 4
+    ids = np.concatenate([z["ids"], z["ids"][::-1]])[:world * Bl]
+    ans = np.concatenate([z["answers"], z["answers"][::-1]])[:world * Bl]
+    idx = dp.shard_of_global_batch(torch.arange(world * Bl), Bl, rank, world).numpy()
+    loss, _, G, _ = O.loss_and_grads(params, cfg, ids[idx], ans[idx])
+    keys = list(params.keys())
+    flat = torch.from_numpy(np.concatenate([G[k].reshape(-1) for k in keys]).astype(np.float32))
+    scale = dp.allreduce_sum_(flat)
+    flat *= scale
+    if rank == 0:
+        np.save(os.path.join(tmp, "dp.npy"), flat.numpy())
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_equals_global_batch_gradient_gloo_world2(tmp_path):
+    """2 ranks (gloo, CPU): shard a global batch, local mean-loss gradients (oracle as the compute
+    engine), one summing all-reduce of the flat arena, scale 1/W == gradient of the global-batch mean."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import bsarec_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "dp.npy"))
+    cfg, params, _, _, z = load_e2e("B_d16_L20_h1")
+    ids = np.concatenate([z["ids"], z["ids"][::-1]])[:8]
+    ans = np.concatenate([z["answers"], z["answers"][::-1]])[:8]
+    _, _, G, _ = O.loss_and_grads(params, cfg, ids, ans)
+    ref = np.concatenate([G[k].reshape(-1) for k in params.keys()])
+    assert rel_l2(got, ref) < 1e-5
