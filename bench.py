@@ -164,28 +164,46 @@ def main():
     out["step_mfma_frac"] = round(flops_seq * a.batch * world * a.steps / dt / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 5)
 
     if rank == 0 and world == 1 and not a.no_roofline:
-        # dominant contraction (FFN dense_1: [B*L, d] x [d, 4d], 2*T*d*4d FLOP per launch), timed with
-        # hipEvents on its launch stream inside real (eager) training steps
-        lib = Lb.load()
-        lib.bsarec_profile_select(Lb.K_FFN1)
-        nprof = 20
-        for _ in range(nprof):
-            _, ids, ans, _, _ = next(stream)
-            trainer._step_eager(ids, ans)
-        torch.cuda.synchronize()
+        # Per-kernel roofline: hipEvent pairs on the launch stream around every launch of one kernel class
+        # inside real (eager) training steps; the class with the largest time per step is the dominant kernel.
         import ctypes as C
-        ms, n = C.c_double(), C.c_int()
-        lib.bsarec_profile_read(C.byref(ms), C.byref(n))
+        lib = Lb.load()
+        d, L, B, N, cb = a.hidden, a.seq_len, a.batch, a.layers, 2
+        T = B * L
+        fused = (d == 64 and L <= 64)
+        if fused:
+            cands = [(Lb.K_FUSED_BWD, "fused_layer_bwd_kernel (whole BSARecBlock input-gradient chain per sequence)",
+                      B * L * (24 * d * d + 8 * L * d + 16 * cb * d)),
+                     (Lb.K_FUSED_FWD, "fused_layer_fwd_kernel (whole BSARecBlock forward per sequence)",
+                      B * L * (24 * d * d + 4 * L * d + 8 * cb * d)),
+                     (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d)]
+        else:
+            cands = [(Lb.K_FFN1, "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)", 2.0 * T * d * 4 * d),
+                     (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d)]
+        rows = []
+        for kclass, name, fl in cands:
+            lib.bsarec_profile_select(kclass)
+            nprof = 10
+            for _ in range(nprof):
+                _, ids, ans, _, _ = next(stream)
+                trainer._step_eager(ids, ans)
+            torch.cuda.synchronize()
+            ms, n = C.c_double(), C.c_int()
+            lib.bsarec_profile_read(C.byref(ms), C.byref(n))
+            if n.value == 0:
+                continue
+            avg_s = ms.value * 1e-3 / n.value
+            rows.append({"kernel": name, "launches_per_step": n.value / nprof, "avg_us": round(avg_s * 1e6, 3),
+                         "us_per_step": round(ms.value * 1e3 / nprof, 2), "flops_per_launch": float(fl),
+                         "achieved": round(fl / avg_s / 1e12, 3)})
         lib.bsarec_profile_select(Lb.K_NONE)
-        T = a.batch * a.seq_len
-        fl = 2.0 * T * a.hidden * 4 * a.hidden
-        avg_s = ms.value * 1e-3 / max(n.value, 1)
-        ach = fl / avg_s / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)",
-                           "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
-                           "launches_timed": n.value, "avg_us": round(avg_s * 1e6, 3),
-                           "flops_per_launch": fl}
+        rows.sort(key=lambda r: -r["us_per_step"])
+        top = rows[0]
+        out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"],
+                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(top["achieved"] / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                           "avg_us": top["avg_us"], "launches_per_step": top["launches_per_step"],
+                           "flops_per_launch": top["flops_per_launch"], "other_kernels": rows[1:]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
     if rank == 0:

@@ -8,7 +8,7 @@ MAX_LAYERS = 16
 ABI_VERSION = 1
 
 (BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX) = range(9)
-K_NONE, K_FFN1, K_FFN2, K_QKV, K_LOGITS, K_DU, K_DW1 = range(7)
+K_NONE, K_FFN1, K_FFN2, K_QKV, K_LOGITS, K_DU, K_DW1, K_FUSED_FWD, K_FUSED_BWD = range(9)
 
 LAYER_FIELDS = ["sqrt_beta", "filter_ln_w", "filter_ln_b", "query_w", "query_b", "key_w", "key_b", "value_w", "value_b",
                 "dense_w", "dense_b", "attn_ln_w", "attn_ln_b", "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b", "ffn_ln_w",
@@ -67,6 +67,7 @@ EXPORTS = {
     "bsarec_freq_layer_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_int] +
                               [C.c_void_p] * 6),
     "bsarec_profile_select": (C.c_int, [C.c_int]),
+    "bsarec_set_fused": (C.c_int, [C.c_int]),
     "bsarec_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 

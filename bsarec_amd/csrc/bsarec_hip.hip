@@ -2,6 +2,7 @@
 #include "../../include/bsarec_hip.h"
 #include "epilogues.h"
 #include "kernels.h"
+#include "fused_layer.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -16,6 +17,8 @@
 // bsarec_plan_create does one dry pass so that the first real pass may already be under graph capture.
 static thread_local bool g_dry = false;
 #define LAUNCH(...) do { if (!g_dry) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+static int g_use_fused = 1;      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long rup(long a, long b) { return (a + b - 1) / b * b; }
@@ -96,7 +99,8 @@ struct bsarec_plan {
     char* ws; size_t ws_bytes;
     uint64_t* state;
     const float* twiddle;
-    int T, Lp, Vp, dh, nblk, nsplit, kchunk, vsplit, vchunk;
+    int T, Lp, Vp, dh, nblk, rows_pb, nsplit, kchunk, vsplit, vchunk;
+    bool fused;        // fused per-sequence block kernels (decided at plan creation)
     bool train;        // mode of the last forward
     // activations kept for backward
     int* ids32;
@@ -132,21 +136,29 @@ static int check_cfg(const bsarec_config_t& c) {
     return 0;
 }
 
+static bool fused_shape_ok(const bsarec_config_t& c) {
+    const int dh = c.hidden / c.heads;
+    return g_use_fused && c.hidden == 64 && c.seq_len <= 64 && c.cutoff_bins <= FUSED_MAX_CB && (dh == 16 || dh == 32 || dh == 64);
+}
+
 static void derive(bsarec_plan& p) {
     const bsarec_config_t& c = p.cfg;
     p.T = c.batch * c.seq_len;
     p.Lp = (int)rup(c.seq_len, 4);
     p.Vp = (int)rup(c.item_size, 4);
     p.dh = c.hidden / c.heads;
-    p.nblk = cdiv(p.T, 64);
-    // split-K over tokens for the weight-gradient products: ~96 slices, 32-aligned chunks
-    long ch = rup(cdiv(p.T, 96), GEMM_BK);
+    p.fused = fused_shape_ok(c);
+    // LayerNorm gamma/beta partials: one row per 64-token block, or one per sequence on the fused path
+    p.nblk = p.fused ? c.batch : cdiv(p.T, 64);
+    p.rows_pb = p.fused ? c.seq_len : 64;
+    // split-K over tokens for the weight-gradient products: ~40 slices, 32-aligned chunks
+    long ch = rup(cdiv(p.T, 40), GEMM_BK);
     if (ch < 64) ch = 64;
     if (ch > 2048) ch = 2048;
     p.kchunk = (int)ch;
     p.nsplit = cdiv(p.T, p.kchunk);
     // split-K over the catalogue for d(h_last) = dlogits . E
-    long vc = rup(cdiv(p.Vp, 128), GEMM_BK);
+    long vc = rup(cdiv(p.Vp, 16), GEMM_BK);
     if (vc < 64) vc = 64;
     p.vchunk = (int)vc;
     p.vsplit = cdiv(p.Vp, p.vchunk);
@@ -356,6 +368,73 @@ static int launch_reduce(const ReduceJob* jobs, int njobs, long maxlen, hipStrea
     return (int)hipGetLastError();
 }
 
+static bool fused_ok(const bsarec_plan& p) { return p.fused; }
+
+static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
+    const bsarec_config_t& c = p.cfg;
+    const bsarec_layer_t& w = p.P.layer[l];
+    LayerBufs& b = p.lb[l];
+    FusedFwdP F;
+    memset(&F, 0, sizeof(F));
+    F.X = p.X[l]; F.Xout = p.X[l + 1];
+    F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.f_b = w.filter_ln_b;
+    F.wq = w.query_w; F.bq = w.query_b; F.wk = w.key_w; F.bk = w.key_b; F.wv = w.value_w; F.bv = w.value_b;
+    F.wo = w.dense_w; F.bo = w.dense_b; F.a_g = w.attn_ln_w; F.a_b = w.attn_ln_b;
+    F.w1 = w.ffn1_w; F.b1 = w.ffn1_b; F.w2 = w.ffn2_w; F.b2 = w.ffn2_b; F.ff_g = w.ffn_ln_w; F.ff_b = w.ffn_ln_b;
+    F.tw = p.twiddle; F.ids32 = p.ids32;
+    F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs; F.ctx = b.ctx;
+    F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.hmix = b.hmix; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
+    F.dsp = b.dsp;
+    F.L = c.seq_len; F.Lp = p.Lp; F.cb = c.cutoff_bins; F.heads = c.heads;
+    F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
+    F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
+    F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    const size_t smem = fused_fwd_smem_bytes();
+#define FUSED_FWD_CASE(DHV) { \
+        static bool attr = false; \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
+        ProfScope prof(BSAREC_K_FUSED_FWD, s); \
+        LAUNCH(fused_layer_fwd_kernel<DHV>, dim3(c.batch), dim3(256), smem, s, F); }
+    if (p.dh == 16) FUSED_FWD_CASE(16) else if (p.dh == 32) FUSED_FWD_CASE(32) else FUSED_FWD_CASE(64)
+#undef FUSED_FWD_CASE
+    return (int)hipGetLastError();
+}
+
+static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, float* dXout, hipStream_t s) {
+    const bsarec_config_t& c = p.cfg;
+    const bsarec_layer_t& w = p.P.layer[l];
+    LayerBufs& b = p.lb[l];
+    const long nb = p.nblk, d = c.hidden;
+    FusedBwdP F;
+    memset(&F, 0, sizeof(F));
+    F.dY = dY; F.dX = dXout; F.X = p.X[l];
+    F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.wq = w.query_w; F.wk = w.key_w; F.wv = w.value_w; F.wo = w.dense_w;
+    F.a_g = w.attn_ln_w; F.w1 = w.ffn1_w; F.w2 = w.ffn2_w; F.ff_g = w.ffn_ln_w; F.tw = p.twiddle;
+    F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
+    F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
+    F.dT = p.dT; F.dU = p.dU; F.dO = p.dO; F.dq = p.dq; F.dk = p.dk; F.dv = p.dv;
+    F.pg_ff = p.part_ln + 0 * nb * d; F.pb_ff = p.part_ln + 1 * nb * d; F.pg_a = p.part_ln + 2 * nb * d;
+    F.pb_a = p.part_ln + 3 * nb * d; F.pg_f = p.part_ln + 4 * nb * d; F.pb_f = p.part_ln + 5 * nb * d;
+    F.pbeta = p.part_beta;
+    F.L = c.seq_len; F.Lp = p.Lp; F.cb = c.cutoff_bins; F.heads = c.heads;
+    F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha);
+    F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
+    F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    const size_t smem = fused_bwd_smem_bytes();
+#define FUSED_BWD_CASE(DHV) { \
+        static bool attr = false; \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
+        ProfScope prof(BSAREC_K_FUSED_BWD, s); \
+        LAUNCH(fused_layer_bwd_kernel<DHV>, dim3(c.batch), dim3(256), smem, s, F); }
+    if (p.dh == 16) FUSED_BWD_CASE(16) else if (p.dh == 32) FUSED_BWD_CASE(32) else FUSED_BWD_CASE(64)
+#undef FUSED_BWD_CASE
+    return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_set_fused(int enable) { g_use_fused = enable ? 1 : 0; return 0; }
+
 extern "C" int bsarec_step_begin(bsarec_plan_t* p, void* stream) {
     if (!p) return -10;
     LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state);
@@ -386,6 +465,10 @@ extern "C" int bsarec_forward(bsarec_plan_t* p, const int64_t* ids, int train, v
         const bsarec_layer_t& w = p->P.layer[l];
         LayerBufs& b = p->lb[l];
         const float* X = p->X[l];
+        if (fused_ok(*p)) {
+            RET(launch_fused_fwd(*p, l, tr, s));
+            continue;
+        }
         // K2 FrequencyLayer
         DISPATCH_LPR(d, RET(launch_freq_fwd<LPR>(X, w.sqrt_beta, w.filter_ln_w, w.filter_ln_b, c.ln_eps,
                                                  make_drop(*p, c.p_hidden, 1 + 4 * l, tr), p->twiddle, B, L, d,
@@ -523,13 +606,16 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         LayerBufs& b = p->lb[l];
         const float* X = p->X[l];
         float* dXout = (dY == p->dXa) ? p->dXb : p->dXa;
+        if (p->fused) {
+            RET(launch_fused_bwd(*p, l, tr, dY, dXout, s));
+        } else {
         // ---- FeedForward backward
         {
             LnBranch a; memset(&a, 0, sizeof(a));
             a.xhat = b.xhat_ff; a.rstd = b.rstd_ff; a.gamma = w.ffn_ln_w; a.in_scale = 1.f;
             a.drop = make_drop(*p, c.p_hidden, 4 + 4 * l, tr); a.dT = p->dT;
             a.pgamma = p->part_ln + 0L * nb * d; a.pbeta = p->part_ln + 1L * nb * d;
-            DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 0>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, 64));
+            DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 0>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, p->rows_pb));
             HIPCHK(hipGetLastError());
         }
         {   // dU = (dT2 . W2) * gelu'(U)
@@ -539,26 +625,12 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
             e.U = b.u; e.ldu = 4 * d;
             RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s, BSAREC_K_DU)));
         }
-        {   // dW2 = dT2^T . gelu(U), db2
-            GemmP g = gemm_defaults(d, 4 * d, T);
-            g.lda = d; g.ldb = 4 * d; g.A[0] = p->dT; g.B[0] = b.u; g.nsplit = ns; g.kchunk = p->kchunk;
-            auto e = epi_linear<false, false, false>(slab_w_ptr(*p, sm.w2), 4 * d);
-            e.c_split = 4L * d * d;
-            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_GELU, true>(g, nox, e, slab_b_ptr(*p, sm.b2), 1, s)));
-        }
         {   // dH = dU . W1 + dz
             GemmP g = gemm_defaults(T, d, 4 * d);
             g.lda = 4 * d; g.ldb = d; g.A[0] = p->dU; g.B[0] = w.ffn1_w;
             auto e = epi_linear<false, true, false>(p->dH, d);
             e.R = p->dz; e.ldr = d;
             RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
-        }
-        {   // dW1 = dU^T . Hmix, db1
-            GemmP g = gemm_defaults(4 * d, d, T);
-            g.lda = 4 * d; g.ldb = d; g.A[0] = p->dU; g.B[0] = b.hmix; g.nsplit = ns; g.kchunk = p->kchunk;
-            auto e = epi_linear<false, false, false>(slab_w_ptr(*p, sm.w1), d);
-            e.c_split = 4L * d * d;
-            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(g, nox, e, slab_b_ptr(*p, sm.b1), 1, s, BSAREC_K_DW1)));
         }
         // ---- mix + the two LayerNorms (attention branch scaled by 1-alpha, filter branch by alpha)
         {
@@ -570,7 +642,7 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
             f.xhat = b.xhat_f; f.rstd = b.rstd_f; f.gamma = w.filter_ln_w; f.in_scale = c.alpha;
             f.drop = make_drop(*p, c.p_hidden, 1 + 4 * l, tr); f.dT = p->dF;
             f.pgamma = p->part_ln + 4L * nb * d; f.pbeta = p->part_ln + 5L * nb * d;
-            DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 1>), dim3(nb), dim3(ROW_THREADS), 0, s, p->dH, a, f, p->dXacc, T, d, 64));
+            DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 1>), dim3(nb), dim3(ROW_THREADS), 0, s, p->dH, a, f, p->dXacc, T, d, p->rows_pb));
             HIPCHK(hipGetLastError());
         }
         // ---- attention backward
@@ -579,13 +651,6 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
             g.lda = d; g.ldb = d; g.A[0] = p->dO; g.B[0] = w.dense_w;
             auto e = epi_linear<false, false, false>(p->dC, d);
             RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
-        }
-        {   // dWo = dO^T . ctx, dbo
-            GemmP g = gemm_defaults(d, d, T);
-            g.lda = d; g.ldb = d; g.A[0] = p->dO; g.B[0] = b.ctx; g.nsplit = ns; g.kchunk = p->kchunk;
-            auto e = epi_linear<false, false, false>(slab_w_ptr(*p, sm.wo), d);
-            e.c_split = (long)d * d;
-            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(g, nox, e, slab_b_ptr(*p, sm.bo), 1, s)));
         }
         XformP xfa = nox; xfa.drop = make_drop(*p, c.p_attn, 2 + 4 * l, tr); xfa.L = L; xfa.Lp = Lp;
         {   // dS = P * (dA - rowsum(dA P)) / sqrt(dh),  dA = (dC . V^T) * keep/(1-p)
@@ -628,19 +693,38 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
             e.R = p->dXacc; e.ldr = d;
             RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
         }
-        {   // dWq, dWk, dWv = {dQ,dK,dV}^T . X  and their bias gradients
-            GemmP g = gemm_defaults(d, d, T);
-            g.lda = d; g.ldb = d; g.nprob = 3; g.nsplit = ns; g.kchunk = p->kchunk;
-            g.A[0] = p->dq; g.A[1] = p->dk; g.A[2] = p->dv;
-            g.B[0] = g.B[1] = g.B[2] = X;
-            auto e = epi_linear<false, false, false>(slab_w_ptr(*p, sm.wq), d);
-            e.C[1] = slab_w_ptr(*p, sm.wk); e.C[2] = slab_w_ptr(*p, sm.wv);
-            e.c_split = (long)d * d;
-            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(g, nox, e, slab_b_ptr(*p, sm.bq), 1, s)));
+        }
+        {   // all six weight gradients + bias gradients of the block: one grouped split-K launch
+            GroupedTN G;
+            memset(&G, 0, sizeof(G));
+            struct Spec { const float* A; long lda; const float* B; long ldb; int M, N; long woff, boff; int gelu; };
+            const Spec sp[6] = {
+                {p->dq, d, X, d, d, d, sm.wq, sm.bq, 0},        {p->dk, d, X, d, d, d, sm.wk, sm.bk, 0},
+                {p->dv, d, X, d, d, d, sm.wv, sm.bv, 0},        {p->dO, d, b.ctx, d, d, d, sm.wo, sm.bo, 0},
+                {p->dU, 4 * d, b.hmix, d, 4 * d, d, sm.w1, sm.b1, 0}, {p->dT, d, b.u, 4 * d, d, 4 * d, sm.w2, sm.b2, 1}};
+            int tiles = 0;
+            for (int i = 0; i < 6; ++i) {
+                GemmP g = gemm_defaults(sp[i].M, sp[i].N, T);
+                g.lda = sp[i].lda; g.ldb = sp[i].ldb; g.A[0] = sp[i].A; g.B[0] = sp[i].B; g.nsplit = ns; g.kchunk = p->kchunk;
+                G.P[i] = g;
+                G.E[i] = epi_linear<false, false, false>(slab_w_ptr(*p, sp[i].woff), sp[i].N);
+                G.E[i].c_split = (long)sp[i].M * sp[i].N;
+                G.bgrad[i] = slab_b_ptr(*p, sp[i].boff);
+                G.tile0[i] = tiles;
+                G.tiles_n[i] = cdiv(sp[i].N, 64);
+                G.b_gelu[i] = sp[i].gelu;
+                tiles += cdiv(sp[i].M, 64) * G.tiles_n[i];
+            }
+            G.tile0[6] = tiles; G.nprob = 6;
+            constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES;
+            ProfScope prof(BSAREC_K_DW1, s);
+            LAUNCH(gemm_grouped_tn_kernel, dim3(tiles, ns), dim3(GEMM_THREADS), smem, s, G);
+            HIPCHK(hipGetLastError());
         }
         // ---- FrequencyLayer backward: completes dX of this layer
-        DISPATCH_LPR(d, RET(launch_freq_bwd<LPR>(X, p->dF, p->dXtmp, w.sqrt_beta, p->twiddle, B, L, d, c.cutoff_bins,
-                                                 dXout, p->part_beta, s)));
+        if (!p->fused)
+            DISPATCH_LPR(d, RET(launch_freq_bwd<LPR>(X, p->dF, p->dXtmp, w.sqrt_beta, p->twiddle, B, L, d, c.cutoff_bins,
+                                                     dXout, p->part_beta, s)));
         // ---- second-stage reductions of this layer's 19 tensors
         RET(launch_reduce(p->jobs + (long)l * p->jobs_per_layer, p->jobs_per_layer, 4L * d * d, s));
         dY = dXout;
@@ -651,13 +735,20 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         a.xhat = p->xhat0; a.rstd = p->rstd0; a.gamma = p->P.ln_w; a.in_scale = 1.f;
         a.drop = make_drop(*p, c.p_hidden, 0, tr); a.dT = nullptr;
         a.pgamma = p->part_ln + 0L * nb * d; a.pbeta = p->part_ln + 1L * nb * d;
-        DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, 64));
+        DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, p->rows_pb));
         HIPCHK(hipGetLastError());
         DISPATCH_LPR(d, {
-            constexpr int RPP = ROW_THREADS / LPR;
-            const int sb = cdiv(T, RPP);
-            LAUNCH(embed_bwd_kernel<LPR>, dim3(sb + L), dim3(ROW_THREADS), 0, s, p->dz, p->ids32, B, L, d,
-                               p->G.item_emb, p->G.pos_emb, sb);
+            constexpr int CHUNK = SCATTER_FLOATS / (LPR * 4);
+            constexpr size_t smem = SCATTER_FLOATS * 4 + 2 * CHUNK * 4;
+            static bool attr = false;
+            if (!attr) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel<LPR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                attr = true;
+            }
+            const int sb = cdiv(T, CHUNK);
+            LAUNCH(embed_bwd_kernel<LPR>, dim3(sb + L), dim3(ROW_THREADS), smem, s, p->dz, p->ids32, B, L, d,
+                   p->G.item_emb, p->G.pos_emb, sb);
             HIPCHK(hipGetLastError());
         });
         RET(launch_reduce(p->jobs + (long)N * p->jobs_per_layer, 2, d, s));

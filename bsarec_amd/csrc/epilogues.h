@@ -150,3 +150,34 @@ struct EpiDS {
         }
     }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Grouped weight-gradient products: up to 6 independent TN split-K problems of different shapes in
+// ONE launch (dWq dWk dWv dWo dW1 dW2 of a BSARecBlock + their bias gradients).  blockIdx.x walks the
+// concatenated 64x64 output tiles, blockIdx.y is the split-K slice.
+// ---------------------------------------------------------------------------------------------
+#define GROUP_MAX 6
+struct GroupedTN {
+    GemmP P[GROUP_MAX];
+    EpiLinear<false, false, false> E[GROUP_MAX];
+    float* bgrad[GROUP_MAX];
+    int tile0[GROUP_MAX + 1];
+    int tiles_n[GROUP_MAX];
+    int b_gelu[GROUP_MAX];          // apply erf-GELU to the B operand while loading (dW2 = dT^T . gelu(U))
+    int nprob;
+};
+
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_grouped_tn_kernel(const GroupedTN G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int p = 0;
+    while (p + 1 < G.nprob && (int)blockIdx.x >= G.tile0[p + 1]) ++p;
+    const int local = blockIdx.x - G.tile0[p];
+    const int bx = local / G.tiles_n[p], by = local % G.tiles_n[p];
+    XformP X;
+    X.L = 0; X.Lp = 0; X.drop.thresh = 0; X.drop.scale = 1.f; X.drop.rng = nullptr; X.drop.site = 0;
+    if (G.b_gelu[p])
+        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_GELU, true>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
+    else
+        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
+}

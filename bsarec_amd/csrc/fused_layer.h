@@ -1,0 +1,718 @@
+// Fused BSARecBlock kernels for the headline shape class (hidden = 64, L <= 64): ONE workgroup per
+// sequence runs a whole block (FrequencyLayer, QKV, attention, dense + LN + alpha-mix, FFN + LN) with
+// the sequence's activations resident in LDS and the weights streamed from L2 straight into MFMA
+// operand registers (no weight staging, no inter-kernel HBM round trips).  src/model/bsarec.py:56-104.
+//
+// MFMA orientation (v_mfma_f32_32x32x2_f32, D = A.B):
+//   * "rows x weights": A = activation rows from LDS (lane = token, one ds_read_b128 per 8-deep k-block
+//     with the k order permuted as in gemm.h), B = weight rows from global (lane = output feature, 16 B
+//     per lane per k-block).  Accumulator: lane = feature column, register = token row.
+//   * attention is computed transposed (S^T = K.Q^T: lane = query, registers = keys) so the softmax is a
+//     reduction over registers plus one cross-half shuffle, and P^T is consumed in place as the B operand
+//     of ctx^T = V^T.P^T (an accumulator tile is a valid B operand of a product that sums over its rows).
+// 4 waves (2 x 2 over a 64-token x 64-feature tile), 1 workgroup per CU (~127 KB LDS).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+#define FS 68          // LDS row stride (floats) of a 64-wide tile: 16-B aligned rows, conflict-free b128 reads
+#define FU 260         // LDS row stride of the 256-wide FFN tile
+#define FUSED_MAX_CB 8
+
+struct FusedFwdP {
+    const float* X; float* Xout;
+    const float *sqrt_beta, *f_g, *f_b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *a_g, *a_b, *w1, *b1, *w2, *b2, *ff_g, *ff_b;
+    const float* tw; const int* ids32;
+    float *xhat_f, *rstd_f, *q, *k, *v, *probs, *ctx, *xhat_a, *rstd_a, *hmix, *u, *xhat_ff, *rstd_ff, *dsp;
+    int L, Lp, cb, heads;
+    float alpha, oma, eps;
+    DropP drop_f, drop_p, drop_o, drop_ff;
+};
+
+__device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// acc += A(rows from LDS) . W^T(rows from global), K = 8*NKB.  sa / gw already point at this lane's row + 4*half.
+template <int NKB>
+__device__ __forceinline__ void mma_rows_w(const float* __restrict__ sa, const float* __restrict__ gw, f32x16& acc) {
+    f32x4 w[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) w[kb] = ld4(gw + 8 * kb);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const f32x4 a = ld4(sa + 8 * kb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
+    }
+}
+
+// LayerNorm row pass over a 64 x 64 LDS tile (16 lanes x float4 per row, 16 rows per pass):
+//   v = (tile + bias) * dropout + residual ; xhat, rstd -> global ; y = gamma*xhat + beta
+//   MIX: y = alpha*dsp + (1-alpha)*y.  Result -> LDS (outL, may be null) and global (outG).
+template <bool MIX>
+__device__ __forceinline__ void ln_rows_64(const float* __restrict__ tile, const float* __restrict__ bias,
+                                           const float* __restrict__ resid, const DropP& drop, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, float eps, const float* __restrict__ dsp,
+                                           float alpha, float oma, long tok0, int L, float* __restrict__ outL,
+                                           float* __restrict__ outG, float* __restrict__ xhatG, float* __restrict__ rstdG) {
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
+    const f32x4 bi = ld4(bias + lc), g = ld4(gamma + lc), be = ld4(beta + lc);
+#pragma unroll
+    for (int r0 = 0; r0 < 64; r0 += 16) {
+        const int r = r0 + lr;
+        const bool ok = r < L;
+        const long e = (tok0 + r) * 64 + lc;
+        f32x4 v = {0, 0, 0, 0};
+        if (ok) v = (ld4(tile + r * FS + lc) + bi) * drop_mult4(drop, (uint64_t)e >> 2) + ld4(resid + r * FS + lc);
+        const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
+        f32x4 dl = {0, 0, 0, 0};
+        if (ok) dl = v - mean;
+        const float var = group_sum<16>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * (1.0f / 64.0f);
+        const float rs = 1.0f / sqrtf(var + eps);
+        f32x4 y = {0, 0, 0, 0};
+        if (ok) {
+            const f32x4 xh = dl * rs;
+            y = g * xh + be;
+            if (MIX) y = alpha * ld4(dsp + r * FS + lc) + oma * y;
+            st4(xhatG + e, xh);
+            st4(outG + e, y);
+            if (lc == 0) rstdG[tok0 + r] = rs;
+        }
+        if (outL) st4(outL + r * FS + lc, y);
+    }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+fused_layer_fwd_kernel(const FusedFwdP P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sX = sm;
+    float* sD = sX + 64 * FS;
+    float* sH = sD + 64 * FS;
+    float* sR = sH + 64 * FS;                   // union: {sQ, sK, sVt, sC} | sU | DFT partials
+    float* sQ = sR;
+    float* sK = sR + 64 * FS;
+    float* sVt = sR + 2 * 64 * FS;              // V transposed: [feature][token]
+    float* sC = sR + 3 * 64 * FS;
+    float* sU = sR;                             // [64][FU]
+    float* sTw = sR + 4 * 64 * FS;              // 128
+    float* sSpec = sTw + 128;                   // FUSED_MAX_CB * 2 * 64
+    int* sIds = reinterpret_cast<int*>(sSpec + FUSED_MAX_CB * 128);   // 64
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int L = P.L, Lp = P.Lp, heads = P.heads;
+    const int b = blockIdx.x;
+    const long tok0 = (long)b * L;
+
+    // ---- phase 0: sequence tile, ids, twiddles -> LDS
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+        f32x4 v = {0, 0, 0, 0};
+        if (r < L) v = ld4(P.X + (tok0 + r) * 64 + c4);
+        st4(sX + r * FS + c4, v);
+    }
+    if (tid < 64) sIds[tid] = tid < L ? P.ids32[tok0 + tid] : 0;
+    if (tid < 2 * L) sTw[tid] = P.tw[tid];
+    __syncthreads();
+
+    // ---- phase 1: FrequencyLayer -> sD (dsp), xhat_f, rstd_f                src/model/bsarec.py:90-104
+    {
+        auto src = [&](int, int t, int c) { return ld4(sX + t * FS + c); };
+        dft_spectrum<16, 1>(src, L, 64, P.cb, sTw, sSpec, sR);
+        const int lr = tid >> 4, lc = (tid & 15) << 2;
+        f32x4 b2 = ld4(P.sqrt_beta + lc);
+        b2 = b2 * b2;
+        const f32x4 g = ld4(P.f_g + lc), be = ld4(P.f_b + lc);
+#pragma unroll
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            const int t = r0 + lr;
+            const bool ok = t < L;
+            const long e = (tok0 + t) * 64 + lc;
+            f32x4 v = {0, 0, 0, 0};
+            if (ok) {
+                const f32x4 xv = ld4(sX + t * FS + lc);
+                const f32x4 low = dft_lowpass_at(sSpec, t, lc, L, 64, P.cb, sTw);
+                v = (low + b2 * (xv - low)) * drop_mult4(P.drop_f, (uint64_t)e >> 2) + xv;
+            }
+            const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
+            f32x4 dl = {0, 0, 0, 0};
+            if (ok) dl = v - mean;
+            const float var = group_sum<16>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * (1.0f / 64.0f);
+            const float rs = 1.0f / sqrtf(var + P.eps);
+            f32x4 y = {0, 0, 0, 0};
+            if (ok) {
+                const f32x4 xh = dl * rs;
+                y = g * xh + be;
+                st4(P.xhat_f + e, xh);
+                if (P.dsp) st4(P.dsp + e, y);
+                if (lc == 0) P.rstd_f[tok0 + t] = rs;
+            }
+            st4(sD + t * FS + lc, y);
+        }
+    }
+    __syncthreads();            // DFT partials (sR) are dead; sQ/sK/sVt may be written
+
+    // ---- phase 2: Q, K, V projections                                     src/model/_modules.py:109-111
+    {
+        const float* sa = sX + (wm * 32 + l31) * FS + 4 * half;
+        const int col = wn * 32 + l31;
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            const float* W = which == 0 ? P.wq : which == 1 ? P.wk : P.wv;
+            const float* bp = which == 0 ? P.bq : which == 1 ? P.bk : P.bv;
+            float* G = which == 0 ? P.q : which == 1 ? P.k : P.v;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            mma_rows_w<8>(sa, W + (long)col * 64 + 4 * half, acc);
+            const float bias = bp[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + rho(r) + 4 * half;
+                const float val = acc[r] + bias;
+                if (which == 0) sQ[row * FS + col] = val;
+                else if (which == 1) sK[row * FS + col] = val;
+                else sVt[col * FS + row] = val;
+                if (row < L) G[(tok0 + row) * 64 + col] = val;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: attention, transposed: lane = query, registers = keys    src/model/_modules.py:118-135
+    {
+        const int nt = (L + 31) >> 5;                        // token tiles actually populated (1 or 2)
+        const float sqrt_dh = sqrtf((float)DH);
+        constexpr int NCT = (DH + 31) / 32;
+        for (int combo = wave; combo < heads * nt; combo += 4) {
+            const int head = combo / nt, qt = combo % nt;
+            const int query = 32 * qt + l31;
+            f32x16 st[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+                if (kt < nt) {
+                    const float* ka = sK + (32 * kt + l31) * FS + head * DH + 4 * half;
+                    const float* qb = sQ + query * FS + head * DH + 4 * half;
+#pragma unroll
+                    for (int kb = 0; kb < DH / 8; ++kb) {
+                        const f32x4 a = ld4(ka + 8 * kb), q4 = ld4(qb + 8 * kb);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], q4[s], st[kt], 0, 0, 0);
+                    }
+                }
+            }
+            // scale, mask (-10000, additive, fp32), softmax over keys
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * kt + rho(r) + 4 * half;
+                    float s = -INFINITY;
+                    if (key < L) s = st[kt][r] / sqrt_dh + ((key <= query && sIds[key] > 0) ? 0.0f : -10000.0f);
+                    st[kt][r] = s;
+                    mx = fmaxf(mx, s);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * kt + rho(r) + 4 * half;
+                    const float e = key < L ? expf(st[kt][r] - mx) : 0.f;
+                    st[kt][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            // probabilities -> global (16 B per lane), then dropout in place
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int key0 = 32 * kt + 8 * g + 4 * half;
+                    f32x4 p = {st[kt][4 * g] / sum, st[kt][4 * g + 1] / sum, st[kt][4 * g + 2] / sum, st[kt][4 * g + 3] / sum};
+                    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+                    if (query < L && key0 < Lp) {
+                        const long e = (((long)b * heads + head) * L + query) * Lp + key0;
+                        st4(P.probs + e, p);
+                        m = drop_mult4(P.drop_p, (uint64_t)e >> 2);
+                    }
+                    p = p * m;
+                    st[kt][4 * g] = p.x; st[kt][4 * g + 1] = p.y; st[kt][4 * g + 2] = p.z; st[kt][4 * g + 3] = p.w;
+                }
+            // ctx^T = V^T . P^T   (P^T accumulators are the B operand as they stand)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                f32x16 cacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+                const bool crow_ok = 32 * ct + l31 < DH;
+                const float* va = sVt + (head * DH + 32 * ct + (crow_ok ? l31 : 0)) * FS + 4 * half;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    if (kt < nt) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 a = ld4(va + 32 * kt + 8 * g);
+                            if (!crow_ok) a = f32x4{0, 0, 0, 0};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], st[kt][4 * g + j], cacc, 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = 32 * ct + 8 * g + 4 * half;
+                    if (c < DH) {
+                        const f32x4 o = {cacc[4 * g], cacc[4 * g + 1], cacc[4 * g + 2], cacc[4 * g + 3]};
+                        st4(sC + query * FS + head * DH + c, o);
+                        if (query < L) st4(P.ctx + (tok0 + query) * 64 + head * DH + c, o);
+                    }
+                }
+            }
+        }
+        // token tiles that no combo covered (L <= 32): keep the context rows defined
+        if (nt == 1)
+            for (int idx = tid; idx < 32 * 16; idx += 256) st4(sC + (32 + (idx >> 4)) * FS + ((idx & 15) << 2), f32x4{0, 0, 0, 0});
+    }
+    __syncthreads();
+
+    // ---- phase 4: dense + dropout + residual + LayerNorm + alpha mix   _modules.py:136-138, bsarec.py:78
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int col = wn * 32 + l31;
+        mma_rows_w<8>(sC + (wm * 32 + l31) * FS + 4 * half, P.wo + (long)col * 64 + 4 * half, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sQ[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];      // sQ is dead: scratch tile
+    }
+    __syncthreads();
+    ln_rows_64<true>(sQ, P.bo, sX, P.drop_o, P.a_g, P.a_b, P.eps, sD, P.alpha, P.oma, tok0, L, sH, P.hmix, P.xhat_a, P.rstd_a);
+    __syncthreads();
+
+    // ---- phase 5: dense_1 + erf-GELU -> sU (and pre-activation u -> global)       _modules.py:62-63
+    {
+        const float* sa = sH + (wm * 32 + l31) * FS + 4 * half;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const int col = blk * 64 + wn * 32 + l31;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            mma_rows_w<8>(sa, P.w1 + (long)col * 64 + 4 * half, acc);
+            const float bias = P.b1[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + rho(r) + 4 * half;
+                const float uv = acc[r] + bias;
+                if (row < L) P.u[(tok0 + row) * 256 + col] = uv;
+                sU[row * FU + col] = gelu_f(uv);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 6: dense_2 + dropout + residual + LayerNorm                        _modules.py:65-67
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int col = wn * 32 + l31;
+        const float* sa = sU + (wm * 32 + l31) * FU + 4 * half;
+        const float* gw = P.w2 + (long)col * 256 + 4 * half;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) mma_rows_w<8>(sa + 64 * ch, gw + 64 * ch, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sX[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];      // sX is dead: scratch tile
+    }
+    __syncthreads();
+    ln_rows_64<false>(sX, P.b2, sH, P.drop_ff, P.ff_g, P.ff_b, P.eps, nullptr, 0.f, 1.f, tok0, L, nullptr, P.Xout,
+                      P.xhat_ff, P.rstd_ff);
+}
+
+static inline size_t fused_fwd_smem_bytes() {
+    return (size_t)(3 * 64 * FS + 4 * 64 * FS + 128 + FUSED_MAX_CB * 128 + 64) * 4;
+}
+
+// =============================================================================================
+// Fused backward of one BSARecBlock (input-gradient chain): one workgroup per sequence.
+//   dY -> [FFN LN bwd] -> dT2 -> dU = (dT2.W2) gelu'(u) -> dH = dU.W1 + dz -> [attn LN / filter LN bwd]
+//   -> dO -> dC = dO.Wo -> per head {dA, dS, dV, dK, dQ} -> dQ.Wq + dK.Wk + dV.Wv + dzA + dzF
+//   -> + FrequencyLayer backward -> dX.
+// Weight/bias gradients are NOT formed here (a per-sequence partial would be 196 KB): dT2, dU, dO, dq, dk,
+// dv are written out for the grouped token-parallel split-K product; LayerNorm gamma/beta and sqrt_beta
+// partials are written per sequence ([B][64]) and reduced by multi_reduce_kernel.
+// "x . W" products need W^T as the MFMA B operand: B[k][j] = W[k][j] is read with coalesced dword loads
+// (lane = j), 4 per 8-deep k-block, k order permuted to match the b128 A fragments.
+// =============================================================================================
+struct FusedBwdP {
+    const float* dY; float* dX; const float* X;
+    const float *sqrt_beta, *f_g, *wq, *wk, *wv, *wo, *a_g, *w1, *w2, *ff_g;
+    const float* tw;
+    const float *xhat_f, *rstd_f, *q, *k, *v, *probs, *xhat_a, *rstd_a, *u, *xhat_ff, *rstd_ff;
+    float *dT, *dU, *dO, *dq, *dk, *dv;                     // operands of the weight-gradient products
+    float *pg_ff, *pb_ff, *pg_a, *pb_a, *pg_f, *pb_f, *pbeta;   // [B][64] partials
+    int L, Lp, cb, heads;
+    float alpha, oma;
+    DropP drop_f, drop_p, drop_o, drop_ff;
+};
+
+template <int NKB, int LDW>
+__device__ __forceinline__ void mma_rows_wT(const float* __restrict__ sa, const float* __restrict__ gw, f32x16& acc) {
+    float w[NKB][4];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w[kb][s] = gw[(8 * kb + s) * LDW];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const f32x4 a = ld4(sa + 8 * kb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
+    }
+}
+
+// column sums held per lane (over this thread's rows) -> [64] partial of the sequence, via LDS scratch [16][64]
+__device__ __forceinline__ void seq_partial_64(const f32x4& v, float* __restrict__ red, float* __restrict__ dst, float scale_by = 1.f,
+                                               const float* __restrict__ mul = nullptr) {
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
+    __syncthreads();
+    st4(red + lr * 64 + lc, v);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g * 64 + threadIdx.x];
+        if (mul) s *= mul[threadIdx.x];
+        dst[threadIdx.x] = s * scale_by;
+    }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+fused_layer_bwd_kernel(const FusedBwdP P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TS = 64 * FS;
+    float* sAcc = sm;                 // T0: dz (FFN) -> dzA + dzF
+    float* sT = sm + TS;              // T1: dT2 -> dO -> DFT spectrum
+    float* sQ = sm + 2 * TS;          // T2..T5 alias dU [64][FU] in the FFN stage and the DFT partials at the end
+    float* sK = sm + 3 * TS;
+    float* sV = sm + 4 * TS;
+    float* sS = sm + 5 * TS;          // dS^T [key][query] of the current head
+    float* sdU = sQ;
+    float* sG = sm + 6 * TS;          // T6: dH -> dC -> dX before the filter term
+    float* sdF = sm + 7 * TS;         // T7
+    float* sPm = sm + 8 * TS;         // T8: Drop(P)^T [key][query] of the current head | reduction scratch | x tile
+    float* sTw = sm + 9 * TS;         // 128
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = tid >> 4, lc = (tid & 15) << 2;
+    const int L = P.L, Lp = P.Lp, heads = P.heads;
+    const int b = blockIdx.x;
+    const long tok0 = (long)b * L;
+    if (tid < 2 * L) sTw[tid] = P.tw[tid];
+
+    // ---- stage A1: FeedForward LayerNorm backward (row pass): dz -> sAcc, dT2 -> sT, global
+    {
+        const f32x4 g = ld4(P.ff_g + lc);
+        f32x4 sg = {0, 0, 0, 0}, sb = sg;
+#pragma unroll
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            const int r = r0 + lr;
+            const bool ok = r < L;
+            const long e = (tok0 + r) * 64 + lc;
+            f32x4 dy = {0, 0, 0, 0}, xh = dy;
+            float rs = 0.f;
+            if (ok) { dy = ld4(P.dY + e); xh = ld4(P.xhat_ff + e); rs = P.rstd_ff[tok0 + r]; }
+            const f32x4 gg = dy * g;
+            const float m1 = group_sum<16>(gg.x + gg.y + gg.z + gg.w) * (1.0f / 64.0f);
+            const float m2 = group_sum<16>(gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w) * (1.0f / 64.0f);
+            const f32x4 dz = rs * (gg - m1 - xh * m2);
+            sg += dy * xh; sb += dy;
+            f32x4 dt = {0, 0, 0, 0};
+            if (ok) { dt = dz * drop_mult4(P.drop_ff, (uint64_t)e >> 2); st4(P.dT + e, dt); }
+            st4(sAcc + r * FS + lc, dz);
+            st4(sT + r * FS + lc, dt);
+        }
+        seq_partial_64(sg, sPm, P.pg_ff + (long)b * 64);
+        seq_partial_64(sb, sPm, P.pb_ff + (long)b * 64);
+    }
+    __syncthreads();
+
+    // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU, global
+    {
+        const float* sa = sT + (wm * 32 + l31) * FS + 4 * half;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const int col = blk * 64 + wn * 32 + l31;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            mma_rows_wT<8, 256>(sa, P.w2 + (long)(4 * half) * 256 + col, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + rho(r) + 4 * half;
+                float du = 0.f;
+                if (row < L) {
+                    du = acc[r] * gelu_grad_f(P.u[(tok0 + row) * 256 + col]);
+                    P.dU[(tok0 + row) * 256 + col] = du;
+                }
+                sdU[row * FU + col] = du;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- stage A3: dH = dU . W1 (+ dz in the row pass below) -> sG
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int col = wn * 32 + l31;
+        const float* sa = sdU + (wm * 32 + l31) * FU + 4 * half;
+        const float* gw = P.w1 + (long)(4 * half) * 64 + col;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) mma_rows_wT<8, 64>(sa + 64 * ch, gw + (long)64 * ch * 64, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sG[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
+    }
+    __syncthreads();
+
+    // ---- stage B1: alpha-mix + attention LayerNorm / filter LayerNorm backward (row pass)
+    //      dO -> sT + global, dF -> sdF, dzA + dzF -> sAcc; q, k, v tiles -> LDS (dU is dead)
+    {
+        const f32x4 ga = ld4(P.a_g + lc), gf = ld4(P.f_g + lc);
+        f32x4 sga = {0, 0, 0, 0}, sba = sga, sgf = sga, sbf = sga;
+#pragma unroll
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            const int r = r0 + lr;
+            const bool ok = r < L;
+            const long e = (tok0 + r) * 64 + lc;
+            f32x4 dh = {0, 0, 0, 0}, xa = dh, xf = dh, q4 = dh, k4 = dh, v4 = dh;
+            float ra = 0.f, rf = 0.f;
+            if (ok) {
+                dh = ld4(sG + r * FS + lc) + ld4(sAcc + r * FS + lc);
+                xa = ld4(P.xhat_a + e); ra = P.rstd_a[tok0 + r];
+                xf = ld4(P.xhat_f + e); rf = P.rstd_f[tok0 + r];
+                q4 = ld4(P.q + e); k4 = ld4(P.k + e); v4 = ld4(P.v + e);
+            }
+            const f32x4 dya = dh * P.oma, dyf = dh * P.alpha;
+            const f32x4 g1 = dya * ga, g2 = dyf * gf;
+            const float m1 = group_sum<16>(g1.x + g1.y + g1.z + g1.w) * (1.0f / 64.0f);
+            const float m2 = group_sum<16>(g1.x * xa.x + g1.y * xa.y + g1.z * xa.z + g1.w * xa.w) * (1.0f / 64.0f);
+            const float n1 = group_sum<16>(g2.x + g2.y + g2.z + g2.w) * (1.0f / 64.0f);
+            const float n2 = group_sum<16>(g2.x * xf.x + g2.y * xf.y + g2.z * xf.z + g2.w * xf.w) * (1.0f / 64.0f);
+            const f32x4 dza = ra * (g1 - m1 - xa * m2), dzf = rf * (g2 - n1 - xf * n2);
+            sga += dya * xa; sba += dya; sgf += dyf * xf; sbf += dyf;
+            f32x4 dO = {0, 0, 0, 0}, dF = dO;
+            if (ok) {
+                dO = dza * drop_mult4(P.drop_o, (uint64_t)e >> 2);
+                dF = dzf * drop_mult4(P.drop_f, (uint64_t)e >> 2);
+                st4(P.dO + e, dO);
+            }
+            st4(sAcc + r * FS + lc, dza + dzf);
+            st4(sT + r * FS + lc, dO);
+            st4(sdF + r * FS + lc, dF);
+            st4(sQ + r * FS + lc, q4); st4(sK + r * FS + lc, k4); st4(sV + r * FS + lc, v4);
+        }
+        seq_partial_64(sga, sPm, P.pg_a + (long)b * 64);
+        seq_partial_64(sba, sPm, P.pb_a + (long)b * 64);
+        seq_partial_64(sgf, sPm, P.pg_f + (long)b * 64);
+        seq_partial_64(sbf, sPm, P.pb_f + (long)b * 64);
+    }
+    __syncthreads();
+
+    // ---- stage B2: dC = dO . Wo -> sG
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int col = wn * 32 + l31;
+        mma_rows_wT<8, 64>(sT + (wm * 32 + l31) * FS + 4 * half, P.wo + (long)(4 * half) * 64 + col, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sG[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
+    }
+    __syncthreads();
+
+    // ---- stage C: attention backward, one head at a time; lane = query, registers = keys
+    {
+        const int nt = (L + 31) >> 5;
+        const float sqrt_dh = sqrtf((float)DH);
+        constexpr int NCT = (DH + 31) / 32;
+        for (int head = 0; head < heads; ++head) {
+            const int hc = head * DH;
+            // C1: waves 0..nt-1 own one query tile each: Drop(P)^T -> sPm, dS^T -> sS   (as [key][query])
+            if (wave < 2) {
+                const int qt = wave;
+                const int query = 32 * qt + l31;
+                f32x16 da[2];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) da[kt][r] = 0.f;
+                    if (kt < nt && qt < nt) {
+                        const float* va = sV + (32 * kt + l31) * FS + hc + 4 * half;
+                        const float* cb_ = sG + query * FS + hc + 4 * half;
+#pragma unroll
+                        for (int kb = 0; kb < DH / 8; ++kb) {
+                            const f32x4 a = ld4(va + 8 * kb), c4 = ld4(cb_ + 8 * kb);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                da[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], c4[s], da[kt], 0, 0, 0);
+                        }
+                    }
+                }
+                f32x16 pr[2];
+                float delta = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int key0 = 32 * kt + 8 * g + 4 * half;
+                        f32x4 p = {0, 0, 0, 0}, m = {0, 0, 0, 0};
+                        if (query < L && key0 < Lp) {
+                            const long e = (((long)b * heads + head) * L + query) * Lp + key0;
+                            p = ld4(P.probs + e);
+                            m = drop_mult4(P.drop_p, (uint64_t)e >> 2);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float dA = da[kt][4 * g + j] * m[j];
+                            delta += dA * p[j];
+                            da[kt][4 * g + j] = dA;
+                            pr[kt][4 * g + j] = p[j];
+                            sPm[(32 * kt + 8 * g + 4 * half + j) * FS + query] = p[j] * m[j];
+                        }
+                    }
+                delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sS[(32 * kt + rho(r) + 4 * half) * FS + query] = pr[kt][r] * (da[kt][r] - delta) / sqrt_dh;
+            }
+            __syncthreads();
+            // C2: 6*NCT output tiles [32 tokens x 32 features]: dQ (rows = queries), dK, dV (rows = keys)
+            f32x16 res[(6 * NCT + 3) / 4];
+#pragma unroll
+            for (int ti = 0; ti < (6 * NCT + 3) / 4; ++ti) {
+                const int t = wave + 4 * ti;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                if (t < 6 * NCT) {
+                    const int kind = t / (2 * NCT), rt = (t / NCT) & 1, ct = t % NCT;
+                    const int c = 32 * ct + l31;
+                    const bool cok = c < DH;
+                    const int cc = hc + (cok ? c : 0);
+                    if (rt < nt) {
+                        for (int kb = 0; kb < 4 * nt; ++kb) {              // K = 32*nt tokens
+                            f32x4 a;
+                            const float* bsrc;
+                            if (kind == 0) {                               // dQ = dS . K : A k-major from sS
+                                const float* ap = sS + (8 * kb + 4 * half) * FS + 32 * rt + l31;
+                                a.x = ap[0]; a.y = ap[FS]; a.z = ap[2 * FS]; a.w = ap[3 * FS];
+                                bsrc = sK;
+                            } else {                                       // dK = dS^T . Q ; dV = Drop(P)^T . dC
+                                a = ld4((kind == 1 ? sS : sPm) + (32 * rt + l31) * FS + 8 * kb + 4 * half);
+                                bsrc = kind == 1 ? sQ : sG;
+                            }
+                            const float* bp = bsrc + (8 * kb + 4 * half) * FS + cc;
+                            float w0 = bp[0], w1 = bp[FS], w2 = bp[2 * FS], w3 = bp[3 * FS];
+                            if (!cok) { w0 = 0.f; w1 = 0.f; w2 = 0.f; w3 = 0.f; }
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w1, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w2, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w3, acc, 0, 0, 0);
+                        }
+                    }
+                }
+                res[ti] = acc;
+            }
+            __syncthreads();                 // every read of this head's q / k / v columns is done
+#pragma unroll
+            for (int ti = 0; ti < (6 * NCT + 3) / 4; ++ti) {
+                const int t = wave + 4 * ti;
+                if (t < 6 * NCT) {
+                    const int kind = t / (2 * NCT), rt = (t / NCT) & 1, ct = t % NCT;
+                    const int c = 32 * ct + l31;
+                    if (c < DH) {
+                        float* sdst = kind == 0 ? sQ : kind == 1 ? sK : sV;      // in place: dq, dk, dv
+                        float* gdst = kind == 0 ? P.dq : kind == 1 ? P.dk : P.dv;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = 32 * rt + rho(r) + 4 * half;
+                            const float val = rt < nt ? res[ti][r] : 0.f;
+                            sdst[row * FS + hc + c] = val;
+                            if (row < L) gdst[(tok0 + row) * 64 + hc + c] = val;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- stage D: dQ.Wq + dK.Wk + dV.Wv + (dzA + dzF) -> sG
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int col = wn * 32 + l31;
+        const int arow = (wm * 32 + l31) * FS + 4 * half;
+        mma_rows_wT<8, 64>(sQ + arow, P.wq + (long)(4 * half) * 64 + col, acc);
+        mma_rows_wT<8, 64>(sK + arow, P.wk + (long)(4 * half) * 64 + col, acc);
+        mma_rows_wT<8, 64>(sV + arow, P.wv + (long)(4 * half) * 64 + col, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + rho(r) + 4 * half;
+            sG[row * FS + col] = acc[r] + sAcc[row * FS + col];
+        }
+    }
+    __syncthreads();
+
+    // ---- stage E: FrequencyLayer backward: dX = sG + beta^2 dF + lowpass((1-beta^2) dF); dbeta partial
+    {
+        float* sXin = sPm;
+        float* spec = sT;                              // [2][cb][2][64]
+        float* part = sQ;                              // 16384 floats over T2..T5
+#pragma unroll
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            const int r = r0 + lr;
+            f32x4 x = {0, 0, 0, 0};
+            if (r < L) x = ld4(P.X + (tok0 + r) * 64 + lc);
+            st4(sXin + r * FS + lc, x);
+        }
+        __syncthreads();
+        const f32x4 bt = ld4(P.sqrt_beta + lc);
+        const f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
+        auto src = [&](int s, int t, int c) {
+            return s == 0 ? ld4(sXin + t * FS + c) : ld4(sdF + t * FS + c) * omb2;
+        };
+        dft_spectrum<16, 2>(src, L, 64, P.cb, sTw, spec, part);
+        f32x4 sb = {0, 0, 0, 0};
+#pragma unroll
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            const int t = r0 + lr;
+            if (t < L) {
+                const f32x4 xv = ld4(sXin + t * FS + lc), df = ld4(sdF + t * FS + lc);
+                const f32x4 lowx = dft_lowpass_at(spec, t, lc, L, 64, P.cb, sTw);
+                const f32x4 lowg = dft_lowpass_at(spec + P.cb * 128, t, lc, L, 64, P.cb, sTw);
+                st4(P.dX + (tok0 + t) * 64 + lc, ld4(sG + t * FS + lc) + b2 * df + lowg);
+                sb += df * (xv - lowx);
+            }
+        }
+        seq_partial_64(sb, part, P.pbeta + (long)b * 64, 2.0f, P.sqrt_beta);
+    }
+}
+
+static inline size_t fused_bwd_smem_bytes() { return (size_t)(9 * 64 * FS + 128) * 4; }

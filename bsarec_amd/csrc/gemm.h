@@ -128,8 +128,9 @@ struct GemmSmem {
 // the kernel
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, class Epi>
-__global__ void __launch_bounds__(GEMM_THREADS)
-gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bgrad /* [nprob][nsplit][M] */) {
+__device__ __forceinline__ void
+gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ bgrad /* [nprob][nsplit][M] */,
+          const int bx, const int by, const int bz, float* __restrict__ smem) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BK = GEMM_BK;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -138,7 +139,6 @@ gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bg
     using SM = GemmSmem<BM, BN, A_KM, B_KM>;
     constexpr int LDAS = A_KM ? BM : BK + 4;
     constexpr int LDBS = B_KM ? BN : BK + 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As0 = smem;
     float* As1 = smem + SM::A_TILE;
     float* Bs0 = smem + 2 * SM::A_TILE;
@@ -149,12 +149,12 @@ gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bg
     const int wrow = (wave / WN) * WTM, wcol = (wave % WN) * WTN;
 
     // blockIdx.z -> (batch, problem, split)
-    int z = blockIdx.z;
+    int z = bz;
     const int split = z % P.nsplit; z /= P.nsplit;
     const int prob = z % P.nprob;
     const int zb = z / P.nprob;
     TileCtx ctx;
-    ctx.m0 = blockIdx.x * BM; ctx.n0 = blockIdx.y * BN; ctx.M = P.M; ctx.N = P.N;
+    ctx.m0 = bx * BM; ctx.n0 = by * BN; ctx.M = P.M; ctx.N = P.N;
     ctx.zb = zb; ctx.b = zb / P.nh; ctx.hh = zb % P.nh; ctx.prob = prob; ctx.split = split;
 
     const long aoff = (long)ctx.b * P.a_sb + (long)ctx.hh * P.a_sh;
@@ -223,7 +223,7 @@ gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bg
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (BGRAD && A_KM && blockIdx.y == 0 && tid < BM) {
+        if (BGRAD && A_KM && by == 0 && tid < BM) {
 #pragma unroll 8
             for (int k = 0; k < BK; ++k) bsum += as[k * LDAS + tid];
         }
@@ -233,7 +233,7 @@ gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bg
         }
         __syncthreads();
     }
-    if (BGRAD && A_KM && blockIdx.y == 0 && tid < BM && ctx.m0 + tid < P.M)
+    if (BGRAD && A_KM && by == 0 && tid < BM && ctx.m0 + tid < P.M)
         bgrad[((long)prob * P.nsplit + split) * P.M + ctx.m0 + tid] = bsum;
 
     // accumulators -> LDS image of the C tile (aliases the staging buffers; the loop's last
@@ -250,4 +250,11 @@ gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bg
             }
     __syncthreads();
     epi.template run<BM, BN>(Cs, ctx);
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, class Epi>
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bgrad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_body<BM, BN, WM, WN, A_KM, B_KM, AXF, BXF, BGRAD, Epi>(P, X, epi, bgrad, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }

@@ -337,7 +337,17 @@ dlast_kernel(const float* __restrict__ slabs, int nsplit, long slab_stride, int 
     f32x4 v = {0, 0, 0, 0};
     if (tok % L == L - 1) {
         const int b = tok / L;
-        for (int s = 0; s < nsplit; ++s) v += ld4(slabs + s * slab_stride + (long)b * d + c);
+        const float* p = slabs + (long)b * d + c;
+        f32x4 a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = f32x4{0, 0, 0, 0};
+        int s = 0;
+        for (; s + 7 < nsplit; s += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += ld4(p + (long)(s + k) * slab_stride);
+        }
+        for (; s < nsplit; ++s) a[0] += ld4(p + (long)s * slab_stride);
+        v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     st4(dX + e, v);
 }
@@ -347,26 +357,54 @@ dlast_kernel(const float* __restrict__ slabs, int nsplit, long slab_stride, int 
 // (padding_idx = 0 suppresses only the lookup gradient, src/model/_abstract_model.py:10).  The dense
 // logits-path dE is already in place; rows are added with full-row (>= 64 B contiguous) f32 atomics.
 // =============================================================================================
+#define SCATTER_FLOATS 16384          // LDS row accumulators per block: chunk = 16384 / (4*LPR) tokens
 template <int LPR>
 __global__ void __launch_bounds__(ROW_THREADS)
 embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, int B, int L, int d,
                  float* __restrict__ dE, float* __restrict__ dPos, int scatter_blocks) {
-    constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4;
-    __shared__ float red[RPP][W];
+    constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4, CHUNK = SCATTER_FLOATS / W;
+    extern __shared__ __attribute__((aligned(16))) float esm[];
+    float* acc = esm;                                   // [CHUNK][W]   (also the dPos reduction scratch)
+    int* sid = reinterpret_cast<int*>(esm + SCATTER_FLOATS);      // [CHUNK]
+    int* lead = sid + CHUNK;                                      // [CHUNK]
     const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
     const bool colok = lc < d;
     if ((int)blockIdx.x < scatter_blocks) {
-        const int tok = blockIdx.x * RPP + lr;
-        if (tok < B * L && colok) {
-            const int id = ids32[tok];
-            if (id != 0) {
-                const f32x4 g = ld4(de + (long)tok * d + lc);
-                float* dst = dE + (long)id * d + lc;
-                unsafeAtomicAdd(dst + 0, g.x); unsafeAtomicAdd(dst + 1, g.y); unsafeAtomicAdd(dst + 2, g.z); unsafeAtomicAdd(dst + 3, g.w);
-            }
+        // Popular items (Zipf) would serialise hundreds of global float atomics on one row.  Each block
+        // owns CHUNK tokens: every token finds the first occurrence of its id in the chunk (its leader),
+        // duplicates are folded into the leader's row with LDS atomics, and each leader then issues ONE
+        // global atomic row add (>= 64 B contiguous per row).
+        const int T = B * L, t0 = blockIdx.x * CHUNK;
+        const int n = min(CHUNK, T - t0);
+        for (int i = threadIdx.x; i < CHUNK; i += ROW_THREADS) sid[i] = i < n ? ids32[t0 + i] : 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < CHUNK; j += ROW_THREADS) {
+            const int id = sid[j];
+            int l = j;
+            for (int i = 0; i < j; ++i) if (sid[i] == id) { l = i; break; }
+            lead[j] = l;
         }
+        __syncthreads();
+        for (int j = lr; j < n; j += RPP)                 // leaders deposit their own row
+            if (colok && sid[j] != 0 && lead[j] == j) st4(acc + j * W + lc, ld4(de + (long)(t0 + j) * d + lc));
+        __syncthreads();
+        for (int j = lr; j < n; j += RPP)                 // duplicates fold into the leader's row
+            if (colok && sid[j] != 0 && lead[j] != j) {
+                const f32x4 g = ld4(de + (long)(t0 + j) * d + lc);
+                float* a = acc + lead[j] * W + lc;
+                atomicAdd(a + 0, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); atomicAdd(a + 3, g.w);
+            }
+        __syncthreads();
+        for (int j = lr; j < n; j += RPP)
+            if (colok && sid[j] != 0 && lead[j] == j) {   // padding_idx = 0: no lookup gradient for id 0
+                const f32x4 g = ld4(acc + j * W + lc);
+                float* dst = dE + (long)sid[j] * d + lc;
+                unsafeAtomicAdd(dst + 0, g.x); unsafeAtomicAdd(dst + 1, g.y);
+                unsafeAtomicAdd(dst + 2, g.z); unsafeAtomicAdd(dst + 3, g.w);
+            }
         return;
     }
+    float (*red)[W] = reinterpret_cast<float (*)[W]>(esm);
     const int t = blockIdx.x - scatter_blocks;       // one block per position
     f32x4 s = {0, 0, 0, 0};
     if (colok)
@@ -391,16 +429,17 @@ multi_reduce_kernel(const ReduceJob* __restrict__ jobs) {
     const ReduceJob j = jobs[blockIdx.y];
     const int i = blockIdx.x * ROW_THREADS + threadIdx.x;
     if (i >= j.len) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    const float* p = j.src + i;
     int s = 0;
-    for (; s + 3 < j.nsplit; s += 4) {
-        a0 += j.src[(long)s * j.stride + i];
-        a1 += j.src[(long)(s + 1) * j.stride + i];
-        a2 += j.src[(long)(s + 2) * j.stride + i];
-        a3 += j.src[(long)(s + 3) * j.stride + i];
+    for (; s + 7 < j.nsplit; s += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += p[(long)(s + k) * j.stride];
     }
-    for (; s < j.nsplit; ++s) a0 += j.src[(long)s * j.stride + i];
-    j.dst[i] = ((a0 + a1) + (a2 + a3)) * j.scale;
+    for (; s < j.nsplit; ++s) a[0] += p[(long)s * j.stride];
+    j.dst[i] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * j.scale;
 }
 
 // =============================================================================================

@@ -146,8 +146,11 @@ int bsarec_freq_layer_bwd(const float *x, const float *dy, const float *xhat, co
  * by hipEventRecord on the launch stream; bsarec_profile_read returns the summed milliseconds and
  * launch count, then resets.  Not for use under graph capture. */
 enum { BSAREC_K_NONE = 0, BSAREC_K_FFN1 = 1, BSAREC_K_FFN2 = 2, BSAREC_K_QKV = 3, BSAREC_K_LOGITS = 4,
-       BSAREC_K_DU = 5, BSAREC_K_DW1 = 6 };
+       BSAREC_K_DU = 5, BSAREC_K_DW1 = 6, BSAREC_K_FUSED_FWD = 7, BSAREC_K_FUSED_BWD = 8 };
 int bsarec_profile_select(int kclass);
+/* Use (1, default) or bypass (0) the fused per-sequence BSARecBlock kernels that exist for hidden = 64,
+ * L <= 64, cutoff_bins <= 8; other shapes always take the generic tiled kernels.  Process-wide. */
+int bsarec_set_fused(int enable);
 int bsarec_profile_read(double *ms_total, int *launches);
 
 #ifdef __cplusplus

@@ -143,3 +143,46 @@ def test_eval_mode_ignores_dropout_and_is_deterministic():
     c = model.forward(ids)
     d = model.forward(ids)
     assert not torch.equal(c, d)                         # new step -> new masks
+
+
+@pytest.mark.parametrize("heads,L,B", [(1, 50, 9), (2, 50, 33), (4, 50, 5), (2, 64, 3), (2, 20, 7), (4, 33, 6)])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
+    """hidden = 64, L <= 64 takes the fused per-sequence BSARecBlock kernels; the same cases are also forced
+    through the generic tiled kernels.  Both must match the oracle (dropout on, shared Philox masks)."""
+    from oracle import bsarec_oracle as O
+    from bsarec_amd import _lib as Lb
+    lib = Lb.load()
+    lib.bsarec_set_fused(fused)
+    try:
+        cfg = O.Config(item_size=131, hidden_size=64, max_seq_length=L, num_hidden_layers=2, num_attention_heads=heads,
+                       c=5, alpha=0.7, hidden_dropout_prob=0.4, attention_probs_dropout_prob=0.3)
+        params = O.init_params(cfg, seed=heads + L)
+        rng = np.random.default_rng(L)
+        for k in params:                                  # non-trivial biases / LN parameters
+            if k.endswith(".bias"):
+                params[k] = (rng.standard_normal(params[k].shape) * 0.05).astype(np.float32)
+            elif "LayerNorm.weight" in k:
+                params[k] = (1 + rng.standard_normal(params[k].shape) * 0.1).astype(np.float32)
+        ids = np.zeros((B, L), dtype=np.int64)
+        for b in range(B):
+            n = 0 if b == 0 else (L if b == 1 else int(rng.integers(1, L + 1)))
+            if n:
+                ids[b, L - n:] = rng.integers(1, 131, size=n)
+        ans = rng.integers(1, 131, size=B).astype(np.int64)
+        model = build_model(cfg, params)
+        model.train()
+        model.set_seed(77)
+        loss = model.calculate_loss(torch.from_numpy(ids).cuda(), torch.from_numpy(ans).cuda(), None, None, None)
+        loss.backward()
+        oloss, _, G, outs = O.loss_and_grads(params, cfg, ids, ans, O.DropoutSpec(True, 77, 1))
+        plan = model._plan(B)
+        for l in range(3):
+            g = plan.view(Lb.BUF_LAYER_OUT, l, (B, L, 64)).cpu().numpy()
+            assert np.isfinite(g).all()
+            assert rel_l2(g, outs[l]) <= 2e-5, (l, rel_l2(g, outs[l]))
+            assert np.abs(g - outs[l]).max() <= 1e-3, (l, np.abs(g - outs[l]).max())
+        assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
+        check_grads(model, G, tol=2e-4)
+    finally:
+        lib.bsarec_set_fused(1)
