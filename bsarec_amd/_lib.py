@@ -68,6 +68,7 @@ EXPORTS = {
                               [C.c_void_p] * 6),
     "bsarec_profile_select": (C.c_int, [C.c_int]),
     "bsarec_set_fused": (C.c_int, [C.c_int]),
+    "bsarec_debug_stamps": (C.c_int, [C.c_void_p]),
     "bsarec_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 

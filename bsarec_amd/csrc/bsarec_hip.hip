@@ -18,6 +18,7 @@
 static thread_local bool g_dry = false;
 #define LAUNCH(...) do { if (!g_dry) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+static long long* g_stamps = nullptr;   // diagnostic stamp buffer (bsarec_debug_stamps)
 static int g_use_fused = 1;      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -389,6 +390,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    F.stamps = g_stamps ? g_stamps + 32 * (2 * l) : nullptr;
     const size_t smem = fused_fwd_smem_bytes();
 #define FUSED_FWD_CASE(DHV) { \
         static bool attr = false; \
@@ -421,6 +423,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha);
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    F.stamps = g_stamps ? g_stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = fused_bwd_smem_bytes();
 #define FUSED_BWD_CASE(DHV) { \
         static bool attr = false; \
@@ -432,6 +435,8 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
 #undef FUSED_BWD_CASE
     return (int)hipGetLastError();
 }
+
+extern "C" int bsarec_debug_stamps(void* dev_buf) { g_stamps = (long long*)dev_buf; return 0; }
 
 extern "C" int bsarec_set_fused(int enable) { g_use_fused = enable ? 1 : 0; return 0; }
 

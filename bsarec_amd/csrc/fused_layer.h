@@ -27,7 +27,10 @@ struct FusedFwdP {
     int L, Lp, cb, heads;
     float alpha, oma, eps;
     DropP drop_f, drop_p, drop_o, drop_ff;
+    long long* stamps;      // diagnostic: per-phase s_memtime of workgroup 0 (null in production)
 };
+
+#define STAMP(i) do { if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[i] = clock64(); } while (0)
 
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
@@ -42,6 +45,99 @@ __device__ __forceinline__ void mma_rows_w(const float* __restrict__ sa, const f
         const f32x4 a = ld4(sa + 8 * kb);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
+    }
+}
+
+
+// ---- pruned DFT with a per-workgroup twiddle table tab[k][t] = (cos, sin)(2 pi k t / L), k < cb, t < 64
+__device__ __forceinline__ void build_twiddle_table(const float* __restrict__ tw, int L, int cb, float* __restrict__ tab) {
+    for (int i = threadIdx.x; i < cb * 64; i += 256) {
+        const int k = i >> 6, t = i & 63;
+        float c = 0.f, s = 0.f;
+        if (t < L) { const int a = (int)((unsigned)(k * t) % (unsigned)L); c = tw[2 * a]; s = tw[2 * a + 1]; }
+        tab[2 * i] = c; tab[2 * i + 1] = s;
+    }
+}
+
+// spectrum of NSRC sources held as 64 x 64 LDS tiles: spec[s][k][re|im][64]; bins are processed 4 at a time,
+// part = scratch [16 row groups][NSRC][4][2][64]
+template <int NSRC, class Src>
+__device__ __forceinline__ void dft_spectrum_tab(const Src& src, int L, int cb, const float* __restrict__ tab,
+                                                 float* __restrict__ spec, float* __restrict__ part) {
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
+    for (int k0 = 0; k0 < cb; k0 += 4) {
+        f32x4 re[NSRC][4], im[NSRC][4];
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { re[s][j] = f32x4{0, 0, 0, 0}; im[s][j] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            const int t = r0 + lr;
+            if (t < L) {
+                f32x4 x[NSRC];
+#pragma unroll
+                for (int s = 0; s < NSRC; ++s) x[s] = src(s, t, lc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j < cb) {
+                        const float c = tab[2 * ((k0 + j) * 64 + t)], sn = tab[2 * ((k0 + j) * 64 + t) + 1];
+#pragma unroll
+                        for (int s = 0; s < NSRC; ++s) { re[s][j] += x[s] * c; im[s][j] -= x[s] * sn; }
+                    }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NSRC; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                st4(part + (((lr * NSRC + s) * 4 + j) * 2 + 0) * 64 + lc, re[s][j]);
+                st4(part + (((lr * NSRC + s) * 4 + j) * 2 + 1) * 64 + lc, im[s][j]);
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NSRC * 4 * 128; i += 256) {
+            const int s = i / 512, j = (i >> 7) & 3, rc = i & 127;
+            if (k0 + j < cb) {
+                float acc = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc += part[g * NSRC * 512 + i];
+                spec[(s * cb + k0 + j) * 128 + rc] = acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ f32x4 lowpass_tab(const float* __restrict__ spec, int t, int lc, int L, int cb,
+                                             const float* __restrict__ tab) {
+    f32x4 low = {0, 0, 0, 0};
+    for (int k = 0; k < cb; ++k) {
+        const float w = (k == 0 || (2 * k == L)) ? 1.0f : 2.0f;
+        const float c = tab[2 * (k * 64 + t)] * w, sn = tab[2 * (k * 64 + t) + 1] * w;
+        low += ld4(spec + (k * 2 + 0) * 64 + lc) * c - ld4(spec + (k * 2 + 1) * 64 + lc) * sn;
+    }
+    return low * (1.0f / (float)L);
+}
+
+// weight fragments: issue the loads of a whole 64-deep K chunk, use them later (latency hidden by the caller)
+__device__ __forceinline__ void load_w8(const float* __restrict__ gw, f32x4 (&w)[8]) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) w[kb] = ld4(gw + 8 * kb);
+}
+__device__ __forceinline__ void mma_w8(const float* __restrict__ sa, const f32x4 (&w)[8], f32x16& acc) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const f32x4 a = ld4(sa + 8 * kb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
+    }
+}
+template <int LDW>
+__device__ __forceinline__ void load_wT8(const float* __restrict__ gw, f32x4 (&w)[8]) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        w[kb].x = gw[(8 * kb + 0) * LDW]; w[kb].y = gw[(8 * kb + 1) * LDW];
+        w[kb].z = gw[(8 * kb + 2) * LDW]; w[kb].w = gw[(8 * kb + 3) * LDW];
     }
 }
 
@@ -94,8 +190,8 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     float* sVt = sR + 2 * 64 * FS;              // V transposed: [feature][token]
     float* sC = sR + 3 * 64 * FS;
     float* sU = sR;                             // [64][FU]
-    float* sTw = sR + 4 * 64 * FS;              // 128
-    float* sSpec = sTw + 128;                   // FUSED_MAX_CB * 2 * 64
+    float* sTab = sR + 4 * 64 * FS;             // FUSED_MAX_CB * 64 * 2
+    float* sSpec = sTab + FUSED_MAX_CB * 128;   // FUSED_MAX_CB * 2 * 64
     int* sIds = reinterpret_cast<int*>(sSpec + FUSED_MAX_CB * 128);   // 64
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,8 +200,14 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     const int L = P.L, Lp = P.Lp, heads = P.heads;
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
+    const int col = wn * 32 + l31;              // this lane's output feature inside a 64-wide block
+    const long wrow = (long)col * 64 + 4 * half;
 
-    // ---- phase 0: sequence tile, ids, twiddles -> LDS
+    STAMP(0);
+    // weight fragments are fetched one product ahead of their use (L2 latency hides behind the previous phase)
+    f32x4 wA[8], wB[8];
+    load_w8(P.wq + wrow, wA);
+    // ---- phase 0: sequence tile, ids, twiddle table -> LDS
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
@@ -114,13 +216,14 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
         st4(sX + r * FS + c4, v);
     }
     if (tid < 64) sIds[tid] = tid < L ? P.ids32[tok0 + tid] : 0;
-    if (tid < 2 * L) sTw[tid] = P.tw[tid];
+    build_twiddle_table(P.tw, L, P.cb, sTab);
     __syncthreads();
 
+    STAMP(1);
     // ---- phase 1: FrequencyLayer -> sD (dsp), xhat_f, rstd_f                src/model/bsarec.py:90-104
     {
         auto src = [&](int, int t, int c) { return ld4(sX + t * FS + c); };
-        dft_spectrum<16, 1>(src, L, 64, P.cb, sTw, sSpec, sR);
+        dft_spectrum_tab<1>(src, L, P.cb, sTab, sSpec, sR);
         const int lr = tid >> 4, lc = (tid & 15) << 2;
         f32x4 b2 = ld4(P.sqrt_beta + lc);
         b2 = b2 * b2;
@@ -133,7 +236,7 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
             f32x4 v = {0, 0, 0, 0};
             if (ok) {
                 const f32x4 xv = ld4(sX + t * FS + lc);
-                const f32x4 low = dft_lowpass_at(sSpec, t, lc, L, 64, P.cb, sTw);
+                const f32x4 low = lowpass_tab(sSpec, t, lc, L, P.cb, sTab);
                 v = (low + b2 * (xv - low)) * drop_mult4(P.drop_f, (uint64_t)e >> 2) + xv;
             }
             const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
@@ -154,33 +257,60 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     }
     __syncthreads();            // DFT partials (sR) are dead; sQ/sK/sVt may be written
 
+    STAMP(2);
     // ---- phase 2: Q, K, V projections                                     src/model/_modules.py:109-111
     {
         const float* sa = sX + (wm * 32 + l31) * FS + 4 * half;
-        const int col = wn * 32 + l31;
+        f32x16 acc;
+        // Q
+        load_w8(P.wk + wrow, wB);
 #pragma unroll
-        for (int which = 0; which < 3; ++which) {
-            const float* W = which == 0 ? P.wq : which == 1 ? P.wk : P.wv;
-            const float* bp = which == 0 ? P.bq : which == 1 ? P.bk : P.bv;
-            float* G = which == 0 ? P.q : which == 1 ? P.k : P.v;
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mma_rows_w<8>(sa, W + (long)col * 64 + 4 * half, acc);
-            const float bias = bp[col];
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_w8(sa, wA, acc);
+        {
+            const float bias = P.bq[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 const float val = acc[r] + bias;
-                if (which == 0) sQ[row * FS + col] = val;
-                else if (which == 1) sK[row * FS + col] = val;
-                else sVt[col * FS + row] = val;
-                if (row < L) G[(tok0 + row) * 64 + col] = val;
+                sQ[row * FS + col] = val;
+                if (row < L) P.q[(tok0 + row) * 64 + col] = val;
+            }
+        }
+        // K
+        load_w8(P.wv + wrow, wA);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_w8(sa, wB, acc);
+        {
+            const float bias = P.bk[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + rho(r) + 4 * half;
+                const float val = acc[r] + bias;
+                sK[row * FS + col] = val;
+                if (row < L) P.k[(tok0 + row) * 64 + col] = val;
+            }
+        }
+        // V (kept transposed in LDS)
+        load_w8(P.wo + wrow, wB);                           // dense weights for phase 4, held across the attention
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_w8(sa, wA, acc);
+        {
+            const float bias = P.bv[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + rho(r) + 4 * half;
+                const float val = acc[r] + bias;
+                sVt[col * FS + row] = val;
+                if (row < L) P.v[(tok0 + row) * 64 + col] = val;
             }
         }
     }
     __syncthreads();
 
+    STAMP(3);
     // ---- phase 3: attention, transposed: lane = query, registers = keys    src/model/_modules.py:118-135
     {
         const int nt = (L + 31) >> 5;                        // token tiles actually populated (1 or 2)
@@ -225,18 +355,19 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = 32 * kt + rho(r) + 4 * half;
-                    const float e = key < L ? expf(st[kt][r] - mx) : 0.f;
+                    const float e = key < L ? __expf(st[kt][r] - mx) : 0.f;
                     st[kt][r] = e;
                     sum += e;
                 }
             sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
             // probabilities -> global (16 B per lane), then dropout in place
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int key0 = 32 * kt + 8 * g + 4 * half;
-                    f32x4 p = {st[kt][4 * g] / sum, st[kt][4 * g + 1] / sum, st[kt][4 * g + 2] / sum, st[kt][4 * g + 3] / sum};
+                    f32x4 p = {st[kt][4 * g] * inv, st[kt][4 * g + 1] * inv, st[kt][4 * g + 2] * inv, st[kt][4 * g + 3] * inv};
                     f32x4 m = {1.f, 1.f, 1.f, 1.f};
                     if (query < L && key0 < Lp) {
                         const long e = (((long)b * heads + head) * L + query) * Lp + key0;
@@ -284,13 +415,14 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     }
     __syncthreads();
 
+    STAMP(4);
     // ---- phase 4: dense + dropout + residual + LayerNorm + alpha mix   _modules.py:136-138, bsarec.py:78
     {
+        load_w8(P.w1 + wrow, wA);                            // first dense_1 block, used in phase 5
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int col = wn * 32 + l31;
-        mma_rows_w<8>(sC + (wm * 32 + l31) * FS + 4 * half, P.wo + (long)col * 64 + 4 * half, acc);
+        mma_w8(sC + (wm * 32 + l31) * FS + 4 * half, wB, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sQ[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];      // sQ is dead: scratch tile
     }
@@ -298,48 +430,60 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     ln_rows_64<true>(sQ, P.bo, sX, P.drop_o, P.a_g, P.a_b, P.eps, sD, P.alpha, P.oma, tok0, L, sH, P.hmix, P.xhat_a, P.rstd_a);
     __syncthreads();
 
+    STAMP(5);
     // ---- phase 5: dense_1 + erf-GELU -> sU (and pre-activation u -> global)       _modules.py:62-63
     {
         const float* sa = sH + (wm * 32 + l31) * FS + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
-            const int col = blk * 64 + wn * 32 + l31;
+            const int c256 = blk * 64 + col;
+            f32x4 (&wcur)[8] = (blk & 1) ? wB : wA;
+            f32x4 (&wnxt)[8] = (blk & 1) ? wA : wB;
+            if (blk < 3) load_w8(P.w1 + (long)(c256 + 64) * 64 + 4 * half, wnxt);
+            else load_w8(P.w2 + (long)col * 256 + 4 * half, wnxt);              // first dense_2 chunk
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mma_rows_w<8>(sa, P.w1 + (long)col * 64 + 4 * half, acc);
-            const float bias = P.b1[col];
+            mma_w8(sa, wcur, acc);
+            const float bias = P.b1[c256];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 const float uv = acc[r] + bias;
-                if (row < L) P.u[(tok0 + row) * 256 + col] = uv;
-                sU[row * FU + col] = gelu_f(uv);
+                if (row < L) P.u[(tok0 + row) * 256 + c256] = uv;
+                sU[row * FU + c256] = gelu_f(uv);
             }
         }
     }
     __syncthreads();
 
+    STAMP(6);
     // ---- phase 6: dense_2 + dropout + residual + LayerNorm                        _modules.py:65-67
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int col = wn * 32 + l31;
         const float* sa = sU + (wm * 32 + l31) * FU + 4 * half;
         const float* gw = P.w2 + (long)col * 256 + 4 * half;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) mma_rows_w<8>(sa + 64 * ch, gw + 64 * ch, acc);
+        for (int ch = 0; ch < 4; ++ch) {                     // chunk 0 sits in wA (loaded at the end of phase 5)
+            f32x4 (&wcur)[8] = (ch & 1) ? wB : wA;
+            f32x4 (&wnxt)[8] = (ch & 1) ? wA : wB;
+            if (ch < 3) load_w8(gw + 64 * (ch + 1), wnxt);
+            mma_w8(sa + 64 * ch, wcur, acc);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) sX[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];      // sX is dead: scratch tile
     }
     __syncthreads();
+    STAMP(7);
     ln_rows_64<false>(sX, P.b2, sH, P.drop_ff, P.ff_g, P.ff_b, P.eps, nullptr, 0.f, 1.f, tok0, L, nullptr, P.Xout,
                       P.xhat_ff, P.rstd_ff);
+    STAMP(8);
 }
 
 static inline size_t fused_fwd_smem_bytes() {
-    return (size_t)(3 * 64 * FS + 4 * 64 * FS + 128 + FUSED_MAX_CB * 128 + 64) * 4;
+    return (size_t)(3 * 64 * FS + 4 * 64 * FS + 2 * FUSED_MAX_CB * 128 + 64) * 4;
 }
 
 // =============================================================================================
@@ -363,6 +507,7 @@ struct FusedBwdP {
     int L, Lp, cb, heads;
     float alpha, oma;
     DropP drop_f, drop_p, drop_o, drop_ff;
+    long long* stamps;
 };
 
 template <int NKB, int LDW>
@@ -411,7 +556,7 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     float* sG = sm + 6 * TS;          // T6: dH -> dC -> dX before the filter term
     float* sdF = sm + 7 * TS;         // T7
     float* sPm = sm + 8 * TS;         // T8: Drop(P)^T [key][query] of the current head | reduction scratch | x tile
-    float* sTw = sm + 9 * TS;         // 128
+    float* sTab = sm + 9 * TS;        // FUSED_MAX_CB * 128
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -419,25 +564,37 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     const int L = P.L, Lp = P.Lp, heads = P.heads;
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
-    if (tid < 2 * L) sTw[tid] = P.tw[tid];
+    const int col = wn * 32 + l31;
+    const int arow = (wm * 32 + l31) * FS + 4 * half;
+
+    STAMP(0);
+    f32x4 wA[8], wB[8];
+    load_wT8<256>(P.w2 + (long)(4 * half) * 256 + col, wA);          // first dU block
+    build_twiddle_table(P.tw, L, P.cb, sTab);
 
     // ---- stage A1: FeedForward LayerNorm backward (row pass): dz -> sAcc, dT2 -> sT, global
     {
         const f32x4 g = ld4(P.ff_g + lc);
         f32x4 sg = {0, 0, 0, 0}, sb = sg;
+        f32x4 dy[4], xh[4];
+        float rs[4];
 #pragma unroll
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-            const int r = r0 + lr;
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * i + lr;
+            const long e = (tok0 + r) * 64 + lc;
+            dy[i] = f32x4{0, 0, 0, 0}; xh[i] = dy[i]; rs[i] = 0.f;
+            if (r < L) { dy[i] = ld4(P.dY + e); xh[i] = ld4(P.xhat_ff + e); rs[i] = P.rstd_ff[tok0 + r]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * i + lr;
             const bool ok = r < L;
             const long e = (tok0 + r) * 64 + lc;
-            f32x4 dy = {0, 0, 0, 0}, xh = dy;
-            float rs = 0.f;
-            if (ok) { dy = ld4(P.dY + e); xh = ld4(P.xhat_ff + e); rs = P.rstd_ff[tok0 + r]; }
-            const f32x4 gg = dy * g;
+            const f32x4 gg = dy[i] * g;
             const float m1 = group_sum<16>(gg.x + gg.y + gg.z + gg.w) * (1.0f / 64.0f);
-            const float m2 = group_sum<16>(gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w) * (1.0f / 64.0f);
-            const f32x4 dz = rs * (gg - m1 - xh * m2);
-            sg += dy * xh; sb += dy;
+            const float m2 = group_sum<16>(gg.x * xh[i].x + gg.y * xh[i].y + gg.z * xh[i].z + gg.w * xh[i].w) * (1.0f / 64.0f);
+            const f32x4 dz = rs[i] * (gg - m1 - xh[i] * m2);
+            sg += dy[i] * xh[i]; sb += dy[i];
             f32x4 dt = {0, 0, 0, 0};
             if (ok) { dt = dz * drop_mult4(P.drop_ff, (uint64_t)e >> 2); st4(P.dT + e, dt); }
             st4(sAcc + r * FS + lc, dz);
@@ -448,71 +605,98 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     }
     __syncthreads();
 
+    STAMP(1);
     // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU, global
     {
-        const float* sa = sT + (wm * 32 + l31) * FS + 4 * half;
+        const float* sa = sT + arow;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
-            const int col = blk * 64 + wn * 32 + l31;
+            const int c256 = blk * 64 + col;
+            f32x4 (&wcur)[8] = (blk & 1) ? wB : wA;
+            f32x4 (&wnxt)[8] = (blk & 1) ? wA : wB;
+            if (blk < 3) load_wT8<256>(P.w2 + (long)(4 * half) * 256 + c256 + 64, wnxt);
+            else load_wT8<64>(P.w1 + (long)(4 * half) * 64 + col, wnxt);          // first dH chunk
+            float uv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + rho(r) + 4 * half;
+                uv[r] = row < L ? P.u[(tok0 + row) * 256 + c256] : 0.f;
+            }
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mma_rows_wT<8, 256>(sa, P.w2 + (long)(4 * half) * 256 + col, acc);
+            mma_w8(sa, wcur, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 float du = 0.f;
                 if (row < L) {
-                    du = acc[r] * gelu_grad_f(P.u[(tok0 + row) * 256 + col]);
-                    P.dU[(tok0 + row) * 256 + col] = du;
+                    du = acc[r] * gelu_grad_f(uv[r]);
+                    P.dU[(tok0 + row) * 256 + c256] = du;
                 }
-                sdU[row * FU + col] = du;
+                sdU[row * FU + c256] = du;
             }
         }
     }
     __syncthreads();
 
+    STAMP(2);
     // ---- stage A3: dH = dU . W1 (+ dz in the row pass below) -> sG
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int col = wn * 32 + l31;
         const float* sa = sdU + (wm * 32 + l31) * FU + 4 * half;
         const float* gw = P.w1 + (long)(4 * half) * 64 + col;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) mma_rows_wT<8, 64>(sa + 64 * ch, gw + (long)64 * ch * 64, acc);
+        for (int ch = 0; ch < 4; ++ch) {                     // chunk 0 sits in wA
+            f32x4 (&wcur)[8] = (ch & 1) ? wB : wA;
+            f32x4 (&wnxt)[8] = (ch & 1) ? wA : wB;
+            if (ch < 3) load_wT8<64>(gw + (long)64 * (ch + 1) * 64, wnxt);
+            else load_wT8<64>(P.wo + (long)(4 * half) * 64 + col, wnxt);         // dense weights for stage B2 (-> wA)
+            mma_w8(sa + 64 * ch, wcur, acc);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) sG[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
     __syncthreads();
 
+    STAMP(3);
     // ---- stage B1: alpha-mix + attention LayerNorm / filter LayerNorm backward (row pass)
     //      dO -> sT + global, dF -> sdF, dzA + dzF -> sAcc; q, k, v tiles -> LDS (dU is dead)
     {
         const f32x4 ga = ld4(P.a_g + lc), gf = ld4(P.f_g + lc);
         f32x4 sga = {0, 0, 0, 0}, sba = sga, sgf = sga, sbf = sga;
+        f32x4 xa[4], xf[4];
+        float ra[4], rf[4];
 #pragma unroll
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-            const int r = r0 + lr;
-            const bool ok = r < L;
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * i + lr;
             const long e = (tok0 + r) * 64 + lc;
-            f32x4 dh = {0, 0, 0, 0}, xa = dh, xf = dh, q4 = dh, k4 = dh, v4 = dh;
-            float ra = 0.f, rf = 0.f;
-            if (ok) {
-                dh = ld4(sG + r * FS + lc) + ld4(sAcc + r * FS + lc);
-                xa = ld4(P.xhat_a + e); ra = P.rstd_a[tok0 + r];
-                xf = ld4(P.xhat_f + e); rf = P.rstd_f[tok0 + r];
+            f32x4 q4 = {0, 0, 0, 0}, k4 = q4, v4 = q4;
+            xa[i] = q4; xf[i] = q4; ra[i] = 0.f; rf[i] = 0.f;
+            if (r < L) {
+                xa[i] = ld4(P.xhat_a + e); ra[i] = P.rstd_a[tok0 + r];
+                xf[i] = ld4(P.xhat_f + e); rf[i] = P.rstd_f[tok0 + r];
                 q4 = ld4(P.q + e); k4 = ld4(P.k + e); v4 = ld4(P.v + e);
             }
+            st4(sQ + r * FS + lc, q4); st4(sK + r * FS + lc, k4); st4(sV + r * FS + lc, v4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * i + lr;
+            const bool ok = r < L;
+            const long e = (tok0 + r) * 64 + lc;
+            f32x4 dh = {0, 0, 0, 0};
+            if (ok) dh = ld4(sG + r * FS + lc) + ld4(sAcc + r * FS + lc);
             const f32x4 dya = dh * P.oma, dyf = dh * P.alpha;
             const f32x4 g1 = dya * ga, g2 = dyf * gf;
             const float m1 = group_sum<16>(g1.x + g1.y + g1.z + g1.w) * (1.0f / 64.0f);
-            const float m2 = group_sum<16>(g1.x * xa.x + g1.y * xa.y + g1.z * xa.z + g1.w * xa.w) * (1.0f / 64.0f);
+            const float m2 = group_sum<16>(g1.x * xa[i].x + g1.y * xa[i].y + g1.z * xa[i].z + g1.w * xa[i].w) * (1.0f / 64.0f);
             const float n1 = group_sum<16>(g2.x + g2.y + g2.z + g2.w) * (1.0f / 64.0f);
-            const float n2 = group_sum<16>(g2.x * xf.x + g2.y * xf.y + g2.z * xf.z + g2.w * xf.w) * (1.0f / 64.0f);
-            const f32x4 dza = ra * (g1 - m1 - xa * m2), dzf = rf * (g2 - n1 - xf * n2);
-            sga += dya * xa; sba += dya; sgf += dyf * xf; sbf += dyf;
+            const float n2 = group_sum<16>(g2.x * xf[i].x + g2.y * xf[i].y + g2.z * xf[i].z + g2.w * xf[i].w) * (1.0f / 64.0f);
+            const f32x4 dza = ra[i] * (g1 - m1 - xa[i] * m2), dzf = rf[i] * (g2 - n1 - xf[i] * n2);
+            sga += dya * xa[i]; sba += dya; sgf += dyf * xf[i]; sbf += dyf;
             f32x4 dO = {0, 0, 0, 0}, dF = dO;
             if (ok) {
                 dO = dza * drop_mult4(P.drop_o, (uint64_t)e >> 2);
@@ -522,7 +706,6 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
             st4(sAcc + r * FS + lc, dza + dzf);
             st4(sT + r * FS + lc, dO);
             st4(sdF + r * FS + lc, dF);
-            st4(sQ + r * FS + lc, q4); st4(sK + r * FS + lc, k4); st4(sV + r * FS + lc, v4);
         }
         seq_partial_64(sga, sPm, P.pg_a + (long)b * 64);
         seq_partial_64(sba, sPm, P.pb_a + (long)b * 64);
@@ -531,29 +714,44 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     }
     __syncthreads();
 
-    // ---- stage B2: dC = dO . Wo -> sG
+    STAMP(4);
+    // ---- stage B2: dC = dO . Wo -> sG            (Wo fragments were fetched into wA during stage A3)
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int col = wn * 32 + l31;
-        mma_rows_wT<8, 64>(sT + (wm * 32 + l31) * FS + 4 * half, P.wo + (long)(4 * half) * 64 + col, acc);
+        mma_w8(sT + arow, wA, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sG[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
     __syncthreads();
 
+    STAMP(5);
     // ---- stage C: attention backward, one head at a time; lane = query, registers = keys
     {
         const int nt = (L + 31) >> 5;
-        const float sqrt_dh = sqrtf((float)DH);
+        const float inv_sqrt_dh = 1.0f / sqrtf((float)DH);
         constexpr int NCT = (DH + 31) / 32;
+        constexpr int NRES = (6 * NCT + 3) / 4;
         for (int head = 0; head < heads; ++head) {
             const int hc = head * DH;
-            // C1: waves 0..nt-1 own one query tile each: Drop(P)^T -> sPm, dS^T -> sS   (as [key][query])
+            // C1: waves 0..1 own one query tile each: Drop(P)^T -> sPm, dS^T -> sS   (as [key][query])
             if (wave < 2) {
                 const int qt = wave;
                 const int query = 32 * qt + l31;
+                f32x4 pp[2][4], mm[2][4];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int key0 = 32 * kt + 8 * g + 4 * half;
+                        pp[kt][g] = f32x4{0, 0, 0, 0}; mm[kt][g] = pp[kt][g];
+                        if (query < L && key0 < Lp) {
+                            const long e = (((long)b * heads + head) * L + query) * Lp + key0;
+                            pp[kt][g] = ld4(P.probs + e);
+                            mm[kt][g] = drop_mult4(P.drop_p, (uint64_t)e >> 2);
+                        }
+                    }
                 f32x16 da[2];
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
@@ -571,40 +769,33 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
                         }
                     }
                 }
-                f32x16 pr[2];
                 float delta = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int key0 = 32 * kt + 8 * g + 4 * half;
-                        f32x4 p = {0, 0, 0, 0}, m = {0, 0, 0, 0};
-                        if (query < L && key0 < Lp) {
-                            const long e = (((long)b * heads + head) * L + query) * Lp + key0;
-                            p = ld4(P.probs + e);
-                            m = drop_mult4(P.drop_p, (uint64_t)e >> 2);
-                        }
+                    for (int g = 0; g < 4; ++g)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float dA = da[kt][4 * g + j] * m[j];
-                            delta += dA * p[j];
+                            const float dA = da[kt][4 * g + j] * mm[kt][g][j];
+                            delta += dA * pp[kt][g][j];
                             da[kt][4 * g + j] = dA;
-                            pr[kt][4 * g + j] = p[j];
-                            sPm[(32 * kt + 8 * g + 4 * half + j) * FS + query] = p[j] * m[j];
+                            sPm[(32 * kt + 8 * g + 4 * half + j) * FS + query] = pp[kt][g][j] * mm[kt][g][j];
                         }
-                    }
                 delta += __shfl_xor(delta, 32, 64);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        sS[(32 * kt + rho(r) + 4 * half) * FS + query] = pr[kt][r] * (da[kt][r] - delta) / sqrt_dh;
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            sS[(32 * kt + 8 * g + 4 * half + j) * FS + query] =
+                                pp[kt][g][j] * (da[kt][4 * g + j] - delta) * inv_sqrt_dh;
             }
             __syncthreads();
             // C2: 6*NCT output tiles [32 tokens x 32 features]: dQ (rows = queries), dK, dV (rows = keys)
-            f32x16 res[(6 * NCT + 3) / 4];
+            f32x16 res[NRES];
 #pragma unroll
-            for (int ti = 0; ti < (6 * NCT + 3) / 4; ++ti) {
+            for (int ti = 0; ti < NRES; ++ti) {
                 const int t = wave + 4 * ti;
                 f32x16 acc;
 #pragma unroll
@@ -615,16 +806,16 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
                     const bool cok = c < DH;
                     const int cc = hc + (cok ? c : 0);
                     if (rt < nt) {
+                        const float* bsrc = kind == 0 ? sK : kind == 1 ? sQ : sG;
+                        const float* asrc = kind == 2 ? sPm : sS;
+#pragma unroll 4
                         for (int kb = 0; kb < 4 * nt; ++kb) {              // K = 32*nt tokens
                             f32x4 a;
-                            const float* bsrc;
                             if (kind == 0) {                               // dQ = dS . K : A k-major from sS
-                                const float* ap = sS + (8 * kb + 4 * half) * FS + 32 * rt + l31;
+                                const float* ap = asrc + (8 * kb + 4 * half) * FS + 32 * rt + l31;
                                 a.x = ap[0]; a.y = ap[FS]; a.z = ap[2 * FS]; a.w = ap[3 * FS];
-                                bsrc = sK;
                             } else {                                       // dK = dS^T . Q ; dV = Drop(P)^T . dC
-                                a = ld4((kind == 1 ? sS : sPm) + (32 * rt + l31) * FS + 8 * kb + 4 * half);
-                                bsrc = kind == 1 ? sQ : sG;
+                                a = ld4(asrc + (32 * rt + l31) * FS + 8 * kb + 4 * half);
                             }
                             const float* bp = bsrc + (8 * kb + 4 * half) * FS + cc;
                             float w0 = bp[0], w1 = bp[FS], w2 = bp[2 * FS], w3 = bp[3 * FS];
@@ -640,7 +831,7 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
             }
             __syncthreads();                 // every read of this head's q / k / v columns is done
 #pragma unroll
-            for (int ti = 0; ti < (6 * NCT + 3) / 4; ++ti) {
+            for (int ti = 0; ti < NRES; ++ti) {
                 const int t = wave + 4 * ti;
                 if (t < 6 * NCT) {
                     const int kind = t / (2 * NCT), rt = (t / NCT) & 1, ct = t % NCT;
@@ -662,16 +853,19 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
         }
     }
 
+    STAMP(6);
     // ---- stage D: dQ.Wq + dK.Wk + dV.Wv + (dzA + dzF) -> sG
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int col = wn * 32 + l31;
-        const int arow = (wm * 32 + l31) * FS + 4 * half;
-        mma_rows_wT<8, 64>(sQ + arow, P.wq + (long)(4 * half) * 64 + col, acc);
-        mma_rows_wT<8, 64>(sK + arow, P.wk + (long)(4 * half) * 64 + col, acc);
-        mma_rows_wT<8, 64>(sV + arow, P.wv + (long)(4 * half) * 64 + col, acc);
+        const long wofs = (long)(4 * half) * 64 + col;
+        load_wT8<64>(P.wq + wofs, wA);
+        load_wT8<64>(P.wk + wofs, wB);
+        mma_w8(sQ + arow, wA, acc);
+        load_wT8<64>(P.wv + wofs, wA);
+        mma_w8(sK + arow, wB, acc);
+        mma_w8(sV + arow, wA, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + rho(r) + 4 * half;
@@ -680,6 +874,7 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     }
     __syncthreads();
 
+    STAMP(7);
     // ---- stage E: FrequencyLayer backward: dX = sG + beta^2 dF + lowpass((1-beta^2) dF); dbeta partial
     {
         float* sXin = sPm;
@@ -698,21 +893,22 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
         auto src = [&](int s, int t, int c) {
             return s == 0 ? ld4(sXin + t * FS + c) : ld4(sdF + t * FS + c) * omb2;
         };
-        dft_spectrum<16, 2>(src, L, 64, P.cb, sTw, spec, part);
+        dft_spectrum_tab<2>(src, L, P.cb, sTab, spec, part);
         f32x4 sb = {0, 0, 0, 0};
 #pragma unroll
         for (int r0 = 0; r0 < 64; r0 += 16) {
             const int t = r0 + lr;
             if (t < L) {
                 const f32x4 xv = ld4(sXin + t * FS + lc), df = ld4(sdF + t * FS + lc);
-                const f32x4 lowx = dft_lowpass_at(spec, t, lc, L, 64, P.cb, sTw);
-                const f32x4 lowg = dft_lowpass_at(spec + P.cb * 128, t, lc, L, 64, P.cb, sTw);
+                const f32x4 lowx = lowpass_tab(spec, t, lc, L, P.cb, sTab);
+                const f32x4 lowg = lowpass_tab(spec + P.cb * 128, t, lc, L, P.cb, sTab);
                 st4(P.dX + (tok0 + t) * 64 + lc, ld4(sG + t * FS + lc) + b2 * df + lowg);
                 sb += df * (xv - lowx);
             }
         }
         seq_partial_64(sb, part, P.pbeta + (long)b * 64, 2.0f, P.sqrt_beta);
     }
+    STAMP(8);
 }
 
-static inline size_t fused_bwd_smem_bytes() { return (size_t)(9 * 64 * FS + 128) * 4; }
+static inline size_t fused_bwd_smem_bytes() { return (size_t)(9 * 64 * FS + FUSED_MAX_CB * 128) * 4; }

@@ -154,7 +154,7 @@ __device__ __forceinline__ void dft_spectrum(const Src& src, int L, int d, int c
             for (int j = 0; j < FREQ_KC; ++j) {
                 const int k = k0 + j;
                 if (k < cb) {
-                    const int a = (int)(((long)k * t) % L);
+                    const int a = (int)((unsigned)(k * t) % (unsigned)L);
                     const float c = tw[2 * a], sn = tw[2 * a + 1];
 #pragma unroll
                     for (int s = 0; s < NSRC; ++s) { re[s][j] += x[s] * c; im[s][j] -= x[s] * sn; }
@@ -186,7 +186,7 @@ __device__ __forceinline__ f32x4 dft_lowpass_at(const float* __restrict__ spec, 
                                                 const float* __restrict__ tw) {
     f32x4 low = {0, 0, 0, 0};
     for (int k = 0; k < cb; ++k) {
-        const int a = (int)(((long)k * t) % L);
+        const int a = (int)((unsigned)(k * t) % (unsigned)L);
         const float w = (k == 0 || (2 * k == L)) ? 1.0f : 2.0f;
         const float c = tw[2 * a] * w, sn = tw[2 * a + 1] * w;
         low += ld4(spec + ((long)k * 2 + 0) * d + lc) * c - ld4(spec + ((long)k * 2 + 1) * d + lc) * sn;

@@ -151,6 +151,9 @@ int bsarec_profile_select(int kclass);
 /* Use (1, default) or bypass (0) the fused per-sequence BSARecBlock kernels that exist for hidden = 64,
  * L <= 64, cutoff_bins <= 8; other shapes always take the generic tiled kernels.  Process-wide. */
 int bsarec_set_fused(int enable);
+/* Diagnostic: device buffer of 32*2*layers int64 that receives per-phase shader-clock stamps of workgroup 0
+ * of the fused kernels (null disables). */
+int bsarec_debug_stamps(void *dev_buf);
 int bsarec_profile_read(double *ms_total, int *launches);
 
 #ifdef __cplusplus
