@@ -84,18 +84,44 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// reductions inside a group of `W` consecutive lanes (W = 16, 32 or 64)
+// all-lanes reductions inside a group of W consecutive lanes (W = 16, 32 or 64).  The 16-lane part is four
+// DPP steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) -- no LDS traffic, unlike __shfl_xor which
+// lowers to ds_bpermute_b32; 32 <-> 32 uses v_permlane32_swap; only the 16 <-> 16 step still permutes via LDS.
 // ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// lanes l and l^32 exchange: after v_permlane32_swap on two copies of v, a = {lo, lo}, b = {hi, hi}.
+// Inline asm with two read-write operands guarantees two distinct registers (the builtin called with the same
+// value twice may be given ONE register, which then merely swaps its own halves); s_nop 1 covers the
+// VALU-write -> permlane-read hazard that hipcc does not pad inside asm.
+__device__ __forceinline__ void halves_of(float v, float& lo, float& hi) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    lo = __builtin_bit_cast(float, a);
+    hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xor32_sum(float v) { float lo, hi; halves_of(v, lo, hi); return lo + hi; }
+__device__ __forceinline__ float xor32_max(float v) { float lo, hi; halves_of(v, lo, hi); return fmaxf(lo, hi); }
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);         // row_half_mirror
+    v += dpp_mov<0x140>(v);         // row_mirror
+    if (W >= 32) v += __shfl_xor(v, 16, 64);
+    if (W >= 64) v = xor32_sum(v);
     return v;
 }
 template <int W>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    if (W >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (W >= 64) v = xor32_max(v);
     return v;
 }
 

@@ -30,7 +30,30 @@ struct FusedFwdP {
     long long* stamps;      // diagnostic: per-phase s_memtime of workgroup 0 (null in production)
 };
 
-#define STAMP(i) do { if (P.stamps && blockIdx.x == 0 && threadIdx.x == 0) P.stamps[i] = clock64(); } while (0)
+
+// Kernel parameters are read from the kernarg segment at their point of use.  With ~40 pointers in the block the
+// compiler otherwise hoists every kernarg load to the entry and spills >100 SGPRs (1400 v_readlane in the ISA);
+// the opaque asm pins each load after the preceding barrier so live ranges stay inside one phase.
+template <class T> struct GlobalPtr { static __device__ __forceinline__ T fix(T v) { return v; } };
+template <class U> struct GlobalPtr<U*> {           // pointers read from memory are generic: re-tag them as global
+    static __device__ __forceinline__ U* fix(U* v) {
+        return (U*)(__attribute__((address_space(1))) U*)v;
+    }
+};
+template <class T>
+__device__ __forceinline__ T kernarg_field(unsigned byte_off) {
+    typedef __attribute__((address_space(4))) const char* kptr_t;
+    typedef __attribute__((address_space(4))) const unsigned* kwords_t;
+    kptr_t base = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    kwords_t w = (kwords_t)(base + byte_off);
+    union { T v; unsigned u[(sizeof(T) + 3) / 4]; } x;
+#pragma unroll
+    for (unsigned i = 0; i < (sizeof(T) + 3) / 4; ++i) x.u[i] = w[i];
+    return GlobalPtr<T>::fix(x.v);
+}
+#define KARG(S, f) kernarg_field<decltype(S::f)>((unsigned)offsetof(S, f))
+#define STAMP(i) do { long long* st_ = KARG(PTYPE, stamps); if (st_ && blockIdx.x == 0 && threadIdx.x == 0) st_[i] = clock64(); } while (0)
 
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
@@ -179,7 +202,11 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tile, const
 
 template <int DH>
 __global__ void __launch_bounds__(256)
-fused_layer_fwd_kernel(const FusedFwdP P) {
+fused_layer_fwd_kernel(const FusedFwdP P_unused) {
+#define PTYPE FusedFwdP
+    const auto R0_L = KARG(FusedFwdP, L);
+    const auto R0_Lp = KARG(FusedFwdP, Lp);
+    const auto R0_heads = KARG(FusedFwdP, heads);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sX = sm;
     float* sD = sX + 64 * FS;
@@ -197,37 +224,51 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int L = P.L, Lp = P.Lp, heads = P.heads;
+    const int L = R0_L, Lp = R0_Lp, heads = R0_heads;
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;              // this lane's output feature inside a 64-wide block
     const long wrow = (long)col * 64 + 4 * half;
 
     STAMP(0);
+    const auto R1_X = KARG(FusedFwdP, X);
+    const auto R1_cb = KARG(FusedFwdP, cb);
+    const auto R1_ids32 = KARG(FusedFwdP, ids32);
+    const auto R1_tw = KARG(FusedFwdP, tw);
+    const auto R1_wq = KARG(FusedFwdP, wq);
     // weight fragments are fetched one product ahead of their use (L2 latency hides behind the previous phase)
     f32x4 wA[8], wB[8];
-    load_w8(P.wq + wrow, wA);
+    load_w8(R1_wq + wrow, wA);
     // ---- phase 0: sequence tile, ids, twiddle table -> LDS
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
         f32x4 v = {0, 0, 0, 0};
-        if (r < L) v = ld4(P.X + (tok0 + r) * 64 + c4);
+        if (r < L) v = ld4(R1_X + (tok0 + r) * 64 + c4);
         st4(sX + r * FS + c4, v);
     }
-    if (tid < 64) sIds[tid] = tid < L ? P.ids32[tok0 + tid] : 0;
-    build_twiddle_table(P.tw, L, P.cb, sTab);
+    if (tid < 64) sIds[tid] = tid < L ? R1_ids32[tok0 + tid] : 0;
+    build_twiddle_table(R1_tw, L, R1_cb, sTab);
     __syncthreads();
 
     STAMP(1);
+    const auto R2_cb = KARG(FusedFwdP, cb);
+    const auto R2_drop_f = KARG(FusedFwdP, drop_f);
+    const auto R2_dsp = KARG(FusedFwdP, dsp);
+    const auto R2_eps = KARG(FusedFwdP, eps);
+    const auto R2_f_b = KARG(FusedFwdP, f_b);
+    const auto R2_f_g = KARG(FusedFwdP, f_g);
+    const auto R2_rstd_f = KARG(FusedFwdP, rstd_f);
+    const auto R2_sqrt_beta = KARG(FusedFwdP, sqrt_beta);
+    const auto R2_xhat_f = KARG(FusedFwdP, xhat_f);
     // ---- phase 1: FrequencyLayer -> sD (dsp), xhat_f, rstd_f                src/model/bsarec.py:90-104
     {
         auto src = [&](int, int t, int c) { return ld4(sX + t * FS + c); };
-        dft_spectrum_tab<1>(src, L, P.cb, sTab, sSpec, sR);
+        dft_spectrum_tab<1>(src, L, R2_cb, sTab, sSpec, sR);
         const int lr = tid >> 4, lc = (tid & 15) << 2;
-        f32x4 b2 = ld4(P.sqrt_beta + lc);
+        f32x4 b2 = ld4(R2_sqrt_beta + lc);
         b2 = b2 * b2;
-        const f32x4 g = ld4(P.f_g + lc), be = ld4(P.f_b + lc);
+        const f32x4 g = ld4(R2_f_g + lc), be = ld4(R2_f_b + lc);
 #pragma unroll
         for (int r0 = 0; r0 < 64; r0 += 16) {
             const int t = r0 + lr;
@@ -236,21 +277,21 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
             f32x4 v = {0, 0, 0, 0};
             if (ok) {
                 const f32x4 xv = ld4(sX + t * FS + lc);
-                const f32x4 low = lowpass_tab(sSpec, t, lc, L, P.cb, sTab);
-                v = (low + b2 * (xv - low)) * drop_mult4(P.drop_f, (uint64_t)e >> 2) + xv;
+                const f32x4 low = lowpass_tab(sSpec, t, lc, L, R2_cb, sTab);
+                v = (low + b2 * (xv - low)) * drop_mult4(R2_drop_f, (uint64_t)e >> 2) + xv;
             }
             const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
             f32x4 dl = {0, 0, 0, 0};
             if (ok) dl = v - mean;
             const float var = group_sum<16>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * (1.0f / 64.0f);
-            const float rs = 1.0f / sqrtf(var + P.eps);
+            const float rs = 1.0f / sqrtf(var + R2_eps);
             f32x4 y = {0, 0, 0, 0};
             if (ok) {
                 const f32x4 xh = dl * rs;
                 y = g * xh + be;
-                st4(P.xhat_f + e, xh);
-                if (P.dsp) st4(P.dsp + e, y);
-                if (lc == 0) P.rstd_f[tok0 + t] = rs;
+                st4(R2_xhat_f + e, xh);
+                if (R2_dsp) st4(R2_dsp + e, y);
+                if (lc == 0) R2_rstd_f[tok0 + t] = rs;
             }
             st4(sD + t * FS + lc, y);
         }
@@ -258,59 +299,71 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     __syncthreads();            // DFT partials (sR) are dead; sQ/sK/sVt may be written
 
     STAMP(2);
+    const auto R3_bk = KARG(FusedFwdP, bk);
+    const auto R3_bq = KARG(FusedFwdP, bq);
+    const auto R3_bv = KARG(FusedFwdP, bv);
+    const auto R3_k = KARG(FusedFwdP, k);
+    const auto R3_q = KARG(FusedFwdP, q);
+    const auto R3_v = KARG(FusedFwdP, v);
+    const auto R3_wk = KARG(FusedFwdP, wk);
+    const auto R3_wo = KARG(FusedFwdP, wo);
+    const auto R3_wv = KARG(FusedFwdP, wv);
     // ---- phase 2: Q, K, V projections                                     src/model/_modules.py:109-111
     {
         const float* sa = sX + (wm * 32 + l31) * FS + 4 * half;
         f32x16 acc;
         // Q
-        load_w8(P.wk + wrow, wB);
+        load_w8(R3_wk + wrow, wB);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         mma_w8(sa, wA, acc);
         {
-            const float bias = P.bq[col];
+            const float bias = R3_bq[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 const float val = acc[r] + bias;
                 sQ[row * FS + col] = val;
-                if (row < L) P.q[(tok0 + row) * 64 + col] = val;
+                if (row < L) R3_q[(tok0 + row) * 64 + col] = val;
             }
         }
         // K
-        load_w8(P.wv + wrow, wA);
+        load_w8(R3_wv + wrow, wA);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         mma_w8(sa, wB, acc);
         {
-            const float bias = P.bk[col];
+            const float bias = R3_bk[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 const float val = acc[r] + bias;
                 sK[row * FS + col] = val;
-                if (row < L) P.k[(tok0 + row) * 64 + col] = val;
+                if (row < L) R3_k[(tok0 + row) * 64 + col] = val;
             }
         }
         // V (kept transposed in LDS)
-        load_w8(P.wo + wrow, wB);                           // dense weights for phase 4, held across the attention
+        load_w8(R3_wo + wrow, wB);                           // dense weights for phase 4, held across the attention
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         mma_w8(sa, wA, acc);
         {
-            const float bias = P.bv[col];
+            const float bias = R3_bv[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 const float val = acc[r] + bias;
                 sVt[col * FS + row] = val;
-                if (row < L) P.v[(tok0 + row) * 64 + col] = val;
+                if (row < L) R3_v[(tok0 + row) * 64 + col] = val;
             }
         }
     }
     __syncthreads();
 
     STAMP(3);
+    const auto R4_ctx = KARG(FusedFwdP, ctx);
+    const auto R4_drop_p = KARG(FusedFwdP, drop_p);
+    const auto R4_probs = KARG(FusedFwdP, probs);
     // ---- phase 3: attention, transposed: lane = query, registers = keys    src/model/_modules.py:118-135
     {
         const int nt = (L + 31) >> 5;                        // token tiles actually populated (1 or 2)
@@ -348,7 +401,7 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
                     st[kt][r] = s;
                     mx = fmaxf(mx, s);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor32_max(mx);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -359,7 +412,7 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
                     st[kt][r] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 32, 64);
+            sum = xor32_sum(sum);
             const float inv = 1.0f / sum;
             // probabilities -> global (16 B per lane), then dropout in place
 #pragma unroll
@@ -371,8 +424,8 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
                     f32x4 m = {1.f, 1.f, 1.f, 1.f};
                     if (query < L && key0 < Lp) {
                         const long e = (((long)b * heads + head) * L + query) * Lp + key0;
-                        st4(P.probs + e, p);
-                        m = drop_mult4(P.drop_p, (uint64_t)e >> 2);
+                        st4(R4_probs + e, p);
+                        m = drop_mult4(R4_drop_p, (uint64_t)e >> 2);
                     }
                     p = p * m;
                     st[kt][4 * g] = p.x; st[kt][4 * g + 1] = p.y; st[kt][4 * g + 2] = p.z; st[kt][4 * g + 3] = p.w;
@@ -404,7 +457,7 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
                     if (c < DH) {
                         const f32x4 o = {cacc[4 * g], cacc[4 * g + 1], cacc[4 * g + 2], cacc[4 * g + 3]};
                         st4(sC + query * FS + head * DH + c, o);
-                        if (query < L) st4(P.ctx + (tok0 + query) * 64 + head * DH + c, o);
+                        if (query < L) st4(R4_ctx + (tok0 + query) * 64 + head * DH + c, o);
                     }
                 }
             }
@@ -416,9 +469,20 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     __syncthreads();
 
     STAMP(4);
+    const auto R5_a_b = KARG(FusedFwdP, a_b);
+    const auto R5_a_g = KARG(FusedFwdP, a_g);
+    const auto R5_alpha = KARG(FusedFwdP, alpha);
+    const auto R5_bo = KARG(FusedFwdP, bo);
+    const auto R5_drop_o = KARG(FusedFwdP, drop_o);
+    const auto R5_eps = KARG(FusedFwdP, eps);
+    const auto R5_hmix = KARG(FusedFwdP, hmix);
+    const auto R5_oma = KARG(FusedFwdP, oma);
+    const auto R5_rstd_a = KARG(FusedFwdP, rstd_a);
+    const auto R5_w1 = KARG(FusedFwdP, w1);
+    const auto R5_xhat_a = KARG(FusedFwdP, xhat_a);
     // ---- phase 4: dense + dropout + residual + LayerNorm + alpha mix   _modules.py:136-138, bsarec.py:78
     {
-        load_w8(P.w1 + wrow, wA);                            // first dense_1 block, used in phase 5
+        load_w8(R5_w1 + wrow, wA);                            // first dense_1 block, used in phase 5
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -427,10 +491,14 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
         for (int r = 0; r < 16; ++r) sQ[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];      // sQ is dead: scratch tile
     }
     __syncthreads();
-    ln_rows_64<true>(sQ, P.bo, sX, P.drop_o, P.a_g, P.a_b, P.eps, sD, P.alpha, P.oma, tok0, L, sH, P.hmix, P.xhat_a, P.rstd_a);
+    ln_rows_64<true>(sQ, R5_bo, sX, R5_drop_o, R5_a_g, R5_a_b, R5_eps, sD, R5_alpha, R5_oma, tok0, L, sH, R5_hmix, R5_xhat_a, R5_rstd_a);
     __syncthreads();
 
     STAMP(5);
+    const auto R6_b1 = KARG(FusedFwdP, b1);
+    const auto R6_u = KARG(FusedFwdP, u);
+    const auto R6_w1 = KARG(FusedFwdP, w1);
+    const auto R6_w2 = KARG(FusedFwdP, w2);
     // ---- phase 5: dense_1 + erf-GELU -> sU (and pre-activation u -> global)       _modules.py:62-63
     {
         const float* sa = sH + (wm * 32 + l31) * FS + 4 * half;
@@ -439,18 +507,18 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
             const int c256 = blk * 64 + col;
             f32x4 (&wcur)[8] = (blk & 1) ? wB : wA;
             f32x4 (&wnxt)[8] = (blk & 1) ? wA : wB;
-            if (blk < 3) load_w8(P.w1 + (long)(c256 + 64) * 64 + 4 * half, wnxt);
-            else load_w8(P.w2 + (long)col * 256 + 4 * half, wnxt);              // first dense_2 chunk
+            if (blk < 3) load_w8(R6_w1 + (long)(c256 + 64) * 64 + 4 * half, wnxt);
+            else load_w8(R6_w2 + (long)col * 256 + 4 * half, wnxt);              // first dense_2 chunk
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             mma_w8(sa, wcur, acc);
-            const float bias = P.b1[c256];
+            const float bias = R6_b1[c256];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 const float uv = acc[r] + bias;
-                if (row < L) P.u[(tok0 + row) * 256 + c256] = uv;
+                if (row < L) R6_u[(tok0 + row) * 256 + c256] = uv;
                 sU[row * FU + c256] = gelu_f(uv);
             }
         }
@@ -458,13 +526,14 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     __syncthreads();
 
     STAMP(6);
+    const auto R7_w2 = KARG(FusedFwdP, w2);
     // ---- phase 6: dense_2 + dropout + residual + LayerNorm                        _modules.py:65-67
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* sa = sU + (wm * 32 + l31) * FU + 4 * half;
-        const float* gw = P.w2 + (long)col * 256 + 4 * half;
+        const float* gw = R7_w2 + (long)col * 256 + 4 * half;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {                     // chunk 0 sits in wA (loaded at the end of phase 5)
             f32x4 (&wcur)[8] = (ch & 1) ? wB : wA;
@@ -477,10 +546,19 @@ fused_layer_fwd_kernel(const FusedFwdP P) {
     }
     __syncthreads();
     STAMP(7);
-    ln_rows_64<false>(sX, P.b2, sH, P.drop_ff, P.ff_g, P.ff_b, P.eps, nullptr, 0.f, 1.f, tok0, L, nullptr, P.Xout,
-                      P.xhat_ff, P.rstd_ff);
+    const auto R8_Xout = KARG(FusedFwdP, Xout);
+    const auto R8_b2 = KARG(FusedFwdP, b2);
+    const auto R8_drop_ff = KARG(FusedFwdP, drop_ff);
+    const auto R8_eps = KARG(FusedFwdP, eps);
+    const auto R8_ff_b = KARG(FusedFwdP, ff_b);
+    const auto R8_ff_g = KARG(FusedFwdP, ff_g);
+    const auto R8_rstd_ff = KARG(FusedFwdP, rstd_ff);
+    const auto R8_xhat_ff = KARG(FusedFwdP, xhat_ff);
+    ln_rows_64<false>(sX, R8_b2, sH, R8_drop_ff, R8_ff_g, R8_ff_b, R8_eps, nullptr, 0.f, 1.f, tok0, L, nullptr, R8_Xout,
+                      R8_xhat_ff, R8_rstd_ff);
     STAMP(8);
 }
+#undef PTYPE
 
 static inline size_t fused_fwd_smem_bytes() {
     return (size_t)(3 * 64 * FS + 4 * 64 * FS + 2 * FUSED_MAX_CB * 128 + 64) * 4;
@@ -543,7 +621,11 @@ __device__ __forceinline__ void seq_partial_64(const f32x4& v, float* __restrict
 
 template <int DH>
 __global__ void __launch_bounds__(256)
-fused_layer_bwd_kernel(const FusedBwdP P) {
+fused_layer_bwd_kernel(const FusedBwdP P_unused) {
+#define PTYPE FusedBwdP
+    const auto R0_L = KARG(FusedBwdP, L);
+    const auto R0_Lp = KARG(FusedBwdP, Lp);
+    const auto R0_heads = KARG(FusedBwdP, heads);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TS = 64 * FS;
     float* sAcc = sm;                 // T0: dz (FFN) -> dzA + dzF
@@ -561,20 +643,31 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = tid >> 4, lc = (tid & 15) << 2;
-    const int L = P.L, Lp = P.Lp, heads = P.heads;
+    const int L = R0_L, Lp = R0_Lp, heads = R0_heads;
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;
     const int arow = (wm * 32 + l31) * FS + 4 * half;
 
     STAMP(0);
+    const auto R1_cb = KARG(FusedBwdP, cb);
+    const auto R1_dT = KARG(FusedBwdP, dT);
+    const auto R1_dY = KARG(FusedBwdP, dY);
+    const auto R1_drop_ff = KARG(FusedBwdP, drop_ff);
+    const auto R1_ff_g = KARG(FusedBwdP, ff_g);
+    const auto R1_pb_ff = KARG(FusedBwdP, pb_ff);
+    const auto R1_pg_ff = KARG(FusedBwdP, pg_ff);
+    const auto R1_rstd_ff = KARG(FusedBwdP, rstd_ff);
+    const auto R1_tw = KARG(FusedBwdP, tw);
+    const auto R1_w2 = KARG(FusedBwdP, w2);
+    const auto R1_xhat_ff = KARG(FusedBwdP, xhat_ff);
     f32x4 wA[8], wB[8];
-    load_wT8<256>(P.w2 + (long)(4 * half) * 256 + col, wA);          // first dU block
-    build_twiddle_table(P.tw, L, P.cb, sTab);
+    load_wT8<256>(R1_w2 + (long)(4 * half) * 256 + col, wA);          // first dU block
+    build_twiddle_table(R1_tw, L, R1_cb, sTab);
 
     // ---- stage A1: FeedForward LayerNorm backward (row pass): dz -> sAcc, dT2 -> sT, global
     {
-        const f32x4 g = ld4(P.ff_g + lc);
+        const f32x4 g = ld4(R1_ff_g + lc);
         f32x4 sg = {0, 0, 0, 0}, sb = sg;
         f32x4 dy[4], xh[4];
         float rs[4];
@@ -583,7 +676,7 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
             const int r = 16 * i + lr;
             const long e = (tok0 + r) * 64 + lc;
             dy[i] = f32x4{0, 0, 0, 0}; xh[i] = dy[i]; rs[i] = 0.f;
-            if (r < L) { dy[i] = ld4(P.dY + e); xh[i] = ld4(P.xhat_ff + e); rs[i] = P.rstd_ff[tok0 + r]; }
+            if (r < L) { dy[i] = ld4(R1_dY + e); xh[i] = ld4(R1_xhat_ff + e); rs[i] = R1_rstd_ff[tok0 + r]; }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -596,16 +689,20 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
             const f32x4 dz = rs[i] * (gg - m1 - xh[i] * m2);
             sg += dy[i] * xh[i]; sb += dy[i];
             f32x4 dt = {0, 0, 0, 0};
-            if (ok) { dt = dz * drop_mult4(P.drop_ff, (uint64_t)e >> 2); st4(P.dT + e, dt); }
+            if (ok) { dt = dz * drop_mult4(R1_drop_ff, (uint64_t)e >> 2); st4(R1_dT + e, dt); }
             st4(sAcc + r * FS + lc, dz);
             st4(sT + r * FS + lc, dt);
         }
-        seq_partial_64(sg, sPm, P.pg_ff + (long)b * 64);
-        seq_partial_64(sb, sPm, P.pb_ff + (long)b * 64);
+        seq_partial_64(sg, sPm, R1_pg_ff + (long)b * 64);
+        seq_partial_64(sb, sPm, R1_pb_ff + (long)b * 64);
     }
     __syncthreads();
 
     STAMP(1);
+    const auto R2_dU = KARG(FusedBwdP, dU);
+    const auto R2_u = KARG(FusedBwdP, u);
+    const auto R2_w1 = KARG(FusedBwdP, w1);
+    const auto R2_w2 = KARG(FusedBwdP, w2);
     // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU, global
     {
         const float* sa = sT + arow;
@@ -614,13 +711,13 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
             const int c256 = blk * 64 + col;
             f32x4 (&wcur)[8] = (blk & 1) ? wB : wA;
             f32x4 (&wnxt)[8] = (blk & 1) ? wA : wB;
-            if (blk < 3) load_wT8<256>(P.w2 + (long)(4 * half) * 256 + c256 + 64, wnxt);
-            else load_wT8<64>(P.w1 + (long)(4 * half) * 64 + col, wnxt);          // first dH chunk
+            if (blk < 3) load_wT8<256>(R2_w2 + (long)(4 * half) * 256 + c256 + 64, wnxt);
+            else load_wT8<64>(R2_w1 + (long)(4 * half) * 64 + col, wnxt);          // first dH chunk
             float uv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
-                uv[r] = row < L ? P.u[(tok0 + row) * 256 + c256] : 0.f;
+                uv[r] = row < L ? R2_u[(tok0 + row) * 256 + c256] : 0.f;
             }
             f32x16 acc;
 #pragma unroll
@@ -632,7 +729,7 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
                 float du = 0.f;
                 if (row < L) {
                     du = acc[r] * gelu_grad_f(uv[r]);
-                    P.dU[(tok0 + row) * 256 + c256] = du;
+                    R2_dU[(tok0 + row) * 256 + c256] = du;
                 }
                 sdU[row * FU + c256] = du;
             }
@@ -641,19 +738,21 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     __syncthreads();
 
     STAMP(2);
+    const auto R3_w1 = KARG(FusedBwdP, w1);
+    const auto R3_wo = KARG(FusedBwdP, wo);
     // ---- stage A3: dH = dU . W1 (+ dz in the row pass below) -> sG
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* sa = sdU + (wm * 32 + l31) * FU + 4 * half;
-        const float* gw = P.w1 + (long)(4 * half) * 64 + col;
+        const float* gw = R3_w1 + (long)(4 * half) * 64 + col;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {                     // chunk 0 sits in wA
             f32x4 (&wcur)[8] = (ch & 1) ? wB : wA;
             f32x4 (&wnxt)[8] = (ch & 1) ? wA : wB;
             if (ch < 3) load_wT8<64>(gw + (long)64 * (ch + 1) * 64, wnxt);
-            else load_wT8<64>(P.wo + (long)(4 * half) * 64 + col, wnxt);         // dense weights for stage B2 (-> wA)
+            else load_wT8<64>(R3_wo + (long)(4 * half) * 64 + col, wnxt);         // dense weights for stage B2 (-> wA)
             mma_w8(sa + 64 * ch, wcur, acc);
         }
 #pragma unroll
@@ -662,10 +761,28 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     __syncthreads();
 
     STAMP(3);
+    const auto R4_a_g = KARG(FusedBwdP, a_g);
+    const auto R4_alpha = KARG(FusedBwdP, alpha);
+    const auto R4_dO = KARG(FusedBwdP, dO);
+    const auto R4_drop_f = KARG(FusedBwdP, drop_f);
+    const auto R4_drop_o = KARG(FusedBwdP, drop_o);
+    const auto R4_f_g = KARG(FusedBwdP, f_g);
+    const auto R4_k = KARG(FusedBwdP, k);
+    const auto R4_oma = KARG(FusedBwdP, oma);
+    const auto R4_pb_a = KARG(FusedBwdP, pb_a);
+    const auto R4_pb_f = KARG(FusedBwdP, pb_f);
+    const auto R4_pg_a = KARG(FusedBwdP, pg_a);
+    const auto R4_pg_f = KARG(FusedBwdP, pg_f);
+    const auto R4_q = KARG(FusedBwdP, q);
+    const auto R4_rstd_a = KARG(FusedBwdP, rstd_a);
+    const auto R4_rstd_f = KARG(FusedBwdP, rstd_f);
+    const auto R4_v = KARG(FusedBwdP, v);
+    const auto R4_xhat_a = KARG(FusedBwdP, xhat_a);
+    const auto R4_xhat_f = KARG(FusedBwdP, xhat_f);
     // ---- stage B1: alpha-mix + attention LayerNorm / filter LayerNorm backward (row pass)
     //      dO -> sT + global, dF -> sdF, dzA + dzF -> sAcc; q, k, v tiles -> LDS (dU is dead)
     {
-        const f32x4 ga = ld4(P.a_g + lc), gf = ld4(P.f_g + lc);
+        const f32x4 ga = ld4(R4_a_g + lc), gf = ld4(R4_f_g + lc);
         f32x4 sga = {0, 0, 0, 0}, sba = sga, sgf = sga, sbf = sga;
         f32x4 xa[4], xf[4];
         float ra[4], rf[4];
@@ -676,9 +793,9 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
             f32x4 q4 = {0, 0, 0, 0}, k4 = q4, v4 = q4;
             xa[i] = q4; xf[i] = q4; ra[i] = 0.f; rf[i] = 0.f;
             if (r < L) {
-                xa[i] = ld4(P.xhat_a + e); ra[i] = P.rstd_a[tok0 + r];
-                xf[i] = ld4(P.xhat_f + e); rf[i] = P.rstd_f[tok0 + r];
-                q4 = ld4(P.q + e); k4 = ld4(P.k + e); v4 = ld4(P.v + e);
+                xa[i] = ld4(R4_xhat_a + e); ra[i] = R4_rstd_a[tok0 + r];
+                xf[i] = ld4(R4_xhat_f + e); rf[i] = R4_rstd_f[tok0 + r];
+                q4 = ld4(R4_q + e); k4 = ld4(R4_k + e); v4 = ld4(R4_v + e);
             }
             st4(sQ + r * FS + lc, q4); st4(sK + r * FS + lc, k4); st4(sV + r * FS + lc, v4);
         }
@@ -689,7 +806,7 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
             const long e = (tok0 + r) * 64 + lc;
             f32x4 dh = {0, 0, 0, 0};
             if (ok) dh = ld4(sG + r * FS + lc) + ld4(sAcc + r * FS + lc);
-            const f32x4 dya = dh * P.oma, dyf = dh * P.alpha;
+            const f32x4 dya = dh * R4_oma, dyf = dh * R4_alpha;
             const f32x4 g1 = dya * ga, g2 = dyf * gf;
             const float m1 = group_sum<16>(g1.x + g1.y + g1.z + g1.w) * (1.0f / 64.0f);
             const float m2 = group_sum<16>(g1.x * xa[i].x + g1.y * xa[i].y + g1.z * xa[i].z + g1.w * xa[i].w) * (1.0f / 64.0f);
@@ -699,18 +816,18 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
             sga += dya * xa[i]; sba += dya; sgf += dyf * xf[i]; sbf += dyf;
             f32x4 dO = {0, 0, 0, 0}, dF = dO;
             if (ok) {
-                dO = dza * drop_mult4(P.drop_o, (uint64_t)e >> 2);
-                dF = dzf * drop_mult4(P.drop_f, (uint64_t)e >> 2);
-                st4(P.dO + e, dO);
+                dO = dza * drop_mult4(R4_drop_o, (uint64_t)e >> 2);
+                dF = dzf * drop_mult4(R4_drop_f, (uint64_t)e >> 2);
+                st4(R4_dO + e, dO);
             }
             st4(sAcc + r * FS + lc, dza + dzf);
             st4(sT + r * FS + lc, dO);
             st4(sdF + r * FS + lc, dF);
         }
-        seq_partial_64(sga, sPm, P.pg_a + (long)b * 64);
-        seq_partial_64(sba, sPm, P.pb_a + (long)b * 64);
-        seq_partial_64(sgf, sPm, P.pg_f + (long)b * 64);
-        seq_partial_64(sbf, sPm, P.pb_f + (long)b * 64);
+        seq_partial_64(sga, sPm, R4_pg_a + (long)b * 64);
+        seq_partial_64(sba, sPm, R4_pb_a + (long)b * 64);
+        seq_partial_64(sgf, sPm, R4_pg_f + (long)b * 64);
+        seq_partial_64(sbf, sPm, R4_pb_f + (long)b * 64);
     }
     __syncthreads();
 
@@ -727,6 +844,11 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     __syncthreads();
 
     STAMP(5);
+    const auto R6_dk = KARG(FusedBwdP, dk);
+    const auto R6_dq = KARG(FusedBwdP, dq);
+    const auto R6_drop_p = KARG(FusedBwdP, drop_p);
+    const auto R6_dv = KARG(FusedBwdP, dv);
+    const auto R6_probs = KARG(FusedBwdP, probs);
     // ---- stage C: attention backward, one head at a time; lane = query, registers = keys
     {
         const int nt = (L + 31) >> 5;
@@ -748,8 +870,8 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
                         pp[kt][g] = f32x4{0, 0, 0, 0}; mm[kt][g] = pp[kt][g];
                         if (query < L && key0 < Lp) {
                             const long e = (((long)b * heads + head) * L + query) * Lp + key0;
-                            pp[kt][g] = ld4(P.probs + e);
-                            mm[kt][g] = drop_mult4(P.drop_p, (uint64_t)e >> 2);
+                            pp[kt][g] = ld4(R6_probs + e);
+                            mm[kt][g] = drop_mult4(R6_drop_p, (uint64_t)e >> 2);
                         }
                     }
                 f32x16 da[2];
@@ -781,7 +903,7 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
                             da[kt][4 * g + j] = dA;
                             sPm[(32 * kt + 8 * g + 4 * half + j) * FS + query] = pp[kt][g][j] * mm[kt][g][j];
                         }
-                delta += __shfl_xor(delta, 32, 64);
+                delta = xor32_sum(delta);
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -838,7 +960,7 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
                     const int c = 32 * ct + l31;
                     if (c < DH) {
                         float* sdst = kind == 0 ? sQ : kind == 1 ? sK : sV;      // in place: dq, dk, dv
-                        float* gdst = kind == 0 ? P.dq : kind == 1 ? P.dk : P.dv;
+                        float* gdst = kind == 0 ? R6_dq : kind == 1 ? R6_dk : R6_dv;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = 32 * rt + rho(r) + 4 * half;
@@ -854,16 +976,19 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     }
 
     STAMP(6);
+    const auto R7_wk = KARG(FusedBwdP, wk);
+    const auto R7_wq = KARG(FusedBwdP, wq);
+    const auto R7_wv = KARG(FusedBwdP, wv);
     // ---- stage D: dQ.Wq + dK.Wk + dV.Wv + (dzA + dzF) -> sG
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const long wofs = (long)(4 * half) * 64 + col;
-        load_wT8<64>(P.wq + wofs, wA);
-        load_wT8<64>(P.wk + wofs, wB);
+        load_wT8<64>(R7_wq + wofs, wA);
+        load_wT8<64>(R7_wk + wofs, wB);
         mma_w8(sQ + arow, wA, acc);
-        load_wT8<64>(P.wv + wofs, wA);
+        load_wT8<64>(R7_wv + wofs, wA);
         mma_w8(sK + arow, wB, acc);
         mma_w8(sV + arow, wA, acc);
 #pragma unroll
@@ -875,6 +1000,11 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
     __syncthreads();
 
     STAMP(7);
+    const auto R8_X = KARG(FusedBwdP, X);
+    const auto R8_cb = KARG(FusedBwdP, cb);
+    const auto R8_dX = KARG(FusedBwdP, dX);
+    const auto R8_pbeta = KARG(FusedBwdP, pbeta);
+    const auto R8_sqrt_beta = KARG(FusedBwdP, sqrt_beta);
     // ---- stage E: FrequencyLayer backward: dX = sG + beta^2 dF + lowpass((1-beta^2) dF); dbeta partial
     {
         float* sXin = sPm;
@@ -884,31 +1014,32 @@ fused_layer_bwd_kernel(const FusedBwdP P) {
         for (int r0 = 0; r0 < 64; r0 += 16) {
             const int r = r0 + lr;
             f32x4 x = {0, 0, 0, 0};
-            if (r < L) x = ld4(P.X + (tok0 + r) * 64 + lc);
+            if (r < L) x = ld4(R8_X + (tok0 + r) * 64 + lc);
             st4(sXin + r * FS + lc, x);
         }
         __syncthreads();
-        const f32x4 bt = ld4(P.sqrt_beta + lc);
+        const f32x4 bt = ld4(R8_sqrt_beta + lc);
         const f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
         auto src = [&](int s, int t, int c) {
             return s == 0 ? ld4(sXin + t * FS + c) : ld4(sdF + t * FS + c) * omb2;
         };
-        dft_spectrum_tab<2>(src, L, P.cb, sTab, spec, part);
+        dft_spectrum_tab<2>(src, L, R8_cb, sTab, spec, part);
         f32x4 sb = {0, 0, 0, 0};
 #pragma unroll
         for (int r0 = 0; r0 < 64; r0 += 16) {
             const int t = r0 + lr;
             if (t < L) {
                 const f32x4 xv = ld4(sXin + t * FS + lc), df = ld4(sdF + t * FS + lc);
-                const f32x4 lowx = lowpass_tab(spec, t, lc, L, P.cb, sTab);
-                const f32x4 lowg = lowpass_tab(spec + P.cb * 128, t, lc, L, P.cb, sTab);
-                st4(P.dX + (tok0 + t) * 64 + lc, ld4(sG + t * FS + lc) + b2 * df + lowg);
+                const f32x4 lowx = lowpass_tab(spec, t, lc, L, R8_cb, sTab);
+                const f32x4 lowg = lowpass_tab(spec + R8_cb * 128, t, lc, L, R8_cb, sTab);
+                st4(R8_dX + (tok0 + t) * 64 + lc, ld4(sG + t * FS + lc) + b2 * df + lowg);
                 sb += df * (xv - lowx);
             }
         }
-        seq_partial_64(sb, part, P.pbeta + (long)b * 64, 2.0f, P.sqrt_beta);
+        seq_partial_64(sb, part, R8_pbeta + (long)b * 64, 2.0f, R8_sqrt_beta);
     }
     STAMP(8);
 }
+#undef PTYPE
 
 static inline size_t fused_bwd_smem_bytes() { return (size_t)(9 * 64 * FS + FUSED_MAX_CB * 128) * 4; }

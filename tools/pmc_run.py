@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""A few C1 training steps (eager) for rocprofv3 --pmc runs."""
+import argparse, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bsarec_amd import BSARecModel
+import bench
+a = argparse.Namespace(item_size=3417, hidden=64, seq_len=50, batch=256, layers=2, heads=2)
+m = BSARecModel(bench.model_args(a)).cuda(); m.train(); m.configure_adam()
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+ids = torch.randint(1, 3417, (256, 50), device="cuda", generator=g)
+lens = torch.randint(0, 51, (256,), device="cuda", generator=g)
+ids[torch.arange(50, device="cuda")[None, :] < (50 - lens)[:, None]] = 0
+ans = torch.randint(1, 3417, (256,), device="cuda", generator=g)
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+    m.train_step(ids, ans)
+torch.cuda.synchronize()
