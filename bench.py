@@ -109,23 +109,62 @@ def main():
     trainer = Trainer(model, batches, None, None, margs, None, use_graph=not a.no_graph, process_group=pg)
     use_graph = trainer.use_graph
 
-    def batch_stream():
-        while True:
-            for b in batches:
-                if b[1].shape[0] == a.batch:           # fixed-size steps only inside the timed region
-                    yield b
+    # steps come straight off the device-resident table: per step ONE C call (gather + fwd + CE + bwd + Adam),
+    # replayed from a hipGraph at N = 1; eager gather + fwd/bwd + all-reduce + Adam for N > 1
+    perm_state = {"perm": None, "pos": 0}
+    B = a.batch
+    cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+    perm_buf = torch.zeros(len(answers), dtype=torch.int64, device=dev)
+    n_local = [0]
 
-    stream = batch_stream()
+    def new_epoch():
+        perm = batches.local_permutation()
+        batches.epoch += 1
+        n_local[0] = (perm.shape[0] // B) * B               # full batches only inside the timed region
+        perm_buf[:perm.shape[0]].copy_(perm)
+        cursor.zero_()
+        perm_state["pos"] = 0
+
+    def step_body():
+        if world == 1:
+            return model.train_step_indexed(batches.inputs, batches.answers, perm_buf, cursor, B)
+        plan = model._plan(B)
+        if not hasattr(plan, "ids_buf"):
+            plan.ids_buf = torch.zeros((B, a.seq_len), dtype=torch.int64, device=dev)
+            plan.ans_buf = torch.zeros((B,), dtype=torch.int64, device=dev)
+        Lb.check(plan.lib.bsarec_gather_batch(batches.inputs.data_ptr(), batches.answers.data_ptr(), perm_buf.data_ptr(),
+                                              perm_buf.shape[0], cursor.data_ptr(), B, a.seq_len, plan.ids_buf.data_ptr(),
+                                              plan.ans_buf.data_ptr(), model._stream()), "bsarec_gather_batch")
+        cursor.add_(B)
+        return trainer._step_eager(plan.ids_buf, plan.ans_buf)
+
+    graph_box = {}
 
     def one_step():
-        _, ids, ans, _, _ = next(stream)
+        if perm_state["pos"] + B > n_local[0]:
+            new_epoch()
+        perm_state["pos"] += B
         if use_graph:
-            first = a.batch not in trainer._graphs
-            loss = trainer._step_graph(ids, ans)
-            if first:
-                loss = trainer._step_graph(ids, ans)
-            return loss
-        return trainer._step_eager(ids, ans)
+            if "g" not in graph_box:
+                model._plan(B)
+                loss0 = step_body()                         # eager: creates static buffers, sets kernel attributes
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    graph_box["loss"] = step_body()
+                graph_box["g"] = g
+                perm_state["pos"] += B
+                g.replay()
+                return graph_box["loss"]
+            graph_box["g"].replay()
+            return graph_box["loss"]
+        return step_body()
+
+    def stream_batches():
+        while True:
+            for bt in batches:
+                if bt[1].shape[0] == a.batch:
+                    yield bt
+    stream = stream_batches()
 
     def barrier():
         if world > 1:

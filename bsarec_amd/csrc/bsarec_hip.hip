@@ -365,7 +365,7 @@ static int launch_freq_bwd(const float* X, const float* dF, const float* dXin, c
 }
 
 static int launch_reduce(const ReduceJob* jobs, int njobs, long maxlen, hipStream_t s) {
-    LAUNCH(multi_reduce_kernel, dim3(cdiv(maxlen, ROW_THREADS), njobs), dim3(ROW_THREADS), 0, s, jobs);
+    LAUNCH(multi_reduce_kernel, dim3(cdiv(maxlen, 64), njobs), dim3(ROW_THREADS), 0, s, jobs);
     return (int)hipGetLastError();
 }
 
@@ -403,7 +403,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, float* dXout, hipStream_t s) {
+static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, float* dXout, hipStream_t s, bool top) {
     const bsarec_config_t& c = p.cfg;
     const bsarec_layer_t& w = p.P.layer[l];
     LayerBufs& b = p.lb[l];
@@ -415,6 +415,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.a_g = w.attn_ln_w; F.w1 = w.ffn1_w; F.w2 = w.ffn2_w; F.ff_g = w.ffn_ln_w; F.tw = p.twiddle;
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
+    if (top) { F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.vsplit; F.dh_stride = (long)c.batch * d; }
     F.dT = p.dT; F.dU = p.dU; F.dO = p.dO; F.dq = p.dq; F.dk = p.dk; F.dv = p.dv;
     F.pg_ff = p.part_ln + 0 * nb * d; F.pb_ff = p.part_ln + 1 * nb * d; F.pg_a = p.part_ln + 2 * nb * d;
     F.pb_a = p.part_ln + 3 * nb * d; F.pg_f = p.part_ln + 4 * nb * d; F.pb_f = p.part_ln + 5 * nb * d;
@@ -442,7 +443,7 @@ extern "C" int bsarec_set_fused(int enable) { g_use_fused = enable ? 1 : 0; retu
 
 extern "C" int bsarec_step_begin(bsarec_plan_t* p, void* stream) {
     if (!p) return -10;
-    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state);
+    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state, (long long*)nullptr, 0);
     return (int)hipGetLastError();
 }
 
@@ -602,9 +603,11 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
     }
     float* dY = (N & 1) ? p->dXb : p->dXa;       // gradient w.r.t. X[l+1]; ping-pong so that dX[0] lands in dXa
-    LAUNCH(dlast_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, p->dlast_slab,
-                       p->vsplit, (long)B * d, T, L, d, dY);
-    HIPCHK(hipGetLastError());
+    if (!p->fused) {      // the fused top-layer backward synthesises this gradient from the slabs itself
+        LAUNCH(dlast_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, p->dlast_slab,
+               p->vsplit, (long)B * d, T, L, d, dY);
+        HIPCHK(hipGetLastError());
+    }
 
     for (int l = N - 1; l >= 0; --l) {
         const bsarec_layer_t& w = p->P.layer[l];
@@ -612,7 +615,7 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         const float* X = p->X[l];
         float* dXout = (dY == p->dXa) ? p->dXb : p->dXa;
         if (p->fused) {
-            RET(launch_fused_bwd(*p, l, tr, dY, dXout, s));
+            RET(launch_fused_bwd(*p, l, tr, dY, dXout, s, l == N - 1));
         } else {
         // ---- FeedForward backward
         {
@@ -776,6 +779,29 @@ extern "C" int bsarec_adam_step(float* params, const float* grads, float* m, flo
     LAUNCH(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, params, grads, m, v, n4, (const uint64_t*)state,
                        b1, b2, eps, wd, gscale);
     return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_gather_batch(const int64_t* table, const int64_t* answers_table, const int64_t* perm, long n_samples,
+                                   const void* cursor, int B, int L, int64_t* ids_out, int64_t* answers_out, void* stream) {
+    if (!table || !answers_table || !perm || !cursor || !ids_out || !answers_out || B < 1 || L < 1) return -10;
+    LAUNCH(gather_batch_kernel, dim3(cdiv((long)B * L, ROW_THREADS)), dim3(ROW_THREADS), 0, (hipStream_t)stream, table,
+           answers_table, perm, n_samples, (const long long*)cursor, B, L, ids_out, answers_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table, const int64_t* answers_table,
+                                         const int64_t* perm, long n_samples, void* cursor, int64_t* ids_buf,
+                                         int64_t* answers_buf, float* params_flat, const float* grads_flat, float* m,
+                                         float* v, long n, float lr, float b1, float b2, float eps, float wd, void* stream) {
+    if (!p) return -10;
+    RET(bsarec_gather_batch(table, answers_table, perm, n_samples, cursor, p->cfg.batch, p->cfg.seq_len, ids_buf,
+                            answers_buf, stream));
+    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state, (long long*)cursor, p->cfg.batch);
+    HIPCHK(hipGetLastError());
+    RET(bsarec_forward(p, ids_buf, 1, stream));
+    RET(bsarec_loss(p, answers_buf, stream));
+    RET(bsarec_backward(p, stream));
+    return bsarec_adam_step(params_flat, grads_flat, m, v, n, p->state, lr, b1, b2, eps, wd, 1.0f, stream);
 }
 
 extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int64_t* answers, float* params_flat,

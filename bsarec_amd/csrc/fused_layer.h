@@ -580,6 +580,7 @@ struct FusedBwdP {
     const float *sqrt_beta, *f_g, *wq, *wk, *wv, *wo, *a_g, *w1, *w2, *ff_g;
     const float* tw;
     const float *xhat_f, *rstd_f, *q, *k, *v, *probs, *xhat_a, *rstd_a, *u, *xhat_ff, *rstd_ff;
+    const float* dh_slabs; int dh_nsplit; long dh_stride;   // top layer: dY = 0 except row L-1 = sum of split-K slabs [s][B][64]
     float *dT, *dU, *dO, *dq, *dk, *dv;                     // operands of the weight-gradient products
     float *pg_ff, *pb_ff, *pg_a, *pb_a, *pg_f, *pb_f, *pbeta;   // [B][64] partials
     int L, Lp, cb, heads;
@@ -653,6 +654,9 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R1_cb = KARG(FusedBwdP, cb);
     const auto R1_dT = KARG(FusedBwdP, dT);
     const auto R1_dY = KARG(FusedBwdP, dY);
+    const auto R1_dh_slabs = KARG(FusedBwdP, dh_slabs);
+    const auto R1_dh_nsplit = KARG(FusedBwdP, dh_nsplit);
+    const auto R1_dh_stride = KARG(FusedBwdP, dh_stride);
     const auto R1_drop_ff = KARG(FusedBwdP, drop_ff);
     const auto R1_ff_g = KARG(FusedBwdP, ff_g);
     const auto R1_pb_ff = KARG(FusedBwdP, pb_ff);
@@ -676,7 +680,13 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             const int r = 16 * i + lr;
             const long e = (tok0 + r) * 64 + lc;
             dy[i] = f32x4{0, 0, 0, 0}; xh[i] = dy[i]; rs[i] = 0.f;
-            if (r < L) { dy[i] = ld4(R1_dY + e); xh[i] = ld4(R1_xhat_ff + e); rs[i] = R1_rstd_ff[tok0 + r]; }
+            if (r < L) {
+                if (R1_dh_slabs) {                          // only the last position feeds the loss (bsarec.py:32)
+                    if (r == L - 1)
+                        for (int sp = 0; sp < R1_dh_nsplit; ++sp) dy[i] += ld4(R1_dh_slabs + sp * R1_dh_stride + (long)b * 64 + lc);
+                } else dy[i] = ld4(R1_dY + e);
+                xh[i] = ld4(R1_xhat_ff + e); rs[i] = R1_rstd_ff[tok0 + r];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -290,6 +290,7 @@ freq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dF, const
 // K7 fused cross-entropy over the materialised logits row: lse, per-row loss, dlogits
 //   loss = mean_b (lse_b - logits[b, answer_b])                              src/model/bsarec.py:33-35
 // =============================================================================================
+#define CE_MAX_PER_THREAD 16           // rows up to 4096 classes stay in registers; longer rows re-read memory
 __global__ void __launch_bounds__(ROW_THREADS)
 ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ answers, int V, int Vp, float inv_b,
                float* __restrict__ dlogits, float* __restrict__ loss_rows) {
@@ -297,8 +298,20 @@ ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ans
     __shared__ float bc;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* row = logits + (long)b * Vp;
+    const bool inreg = V <= CE_MAX_PER_THREAD * ROW_THREADS;
+    float x[CE_MAX_PER_THREAD];
     float mx = -INFINITY;
-    for (int v = tid; v < V; v += ROW_THREADS) mx = fmaxf(mx, row[v]);
+    if (inreg) {
+#pragma unroll
+        for (int k = 0; k < CE_MAX_PER_THREAD; ++k) {
+            const int v = tid + k * ROW_THREADS;
+            x[k] = v < V ? row[v] : -INFINITY;
+        }
+#pragma unroll
+        for (int k = 0; k < CE_MAX_PER_THREAD; ++k) mx = fmaxf(mx, x[k]);
+    } else {
+        for (int v = tid; v < V; v += ROW_THREADS) mx = fmaxf(mx, row[v]);
+    }
     mx = group_max<64>(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
@@ -306,7 +319,12 @@ ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ans
     __syncthreads();
     mx = bc;
     float s = 0.f;
-    for (int v = tid; v < V; v += ROW_THREADS) s += expf(row[v] - mx);
+    if (inreg) {
+#pragma unroll
+        for (int k = 0; k < CE_MAX_PER_THREAD; ++k) s += expf(x[k] - mx);      // exp(-inf) = 0 for the tail
+    } else {
+        for (int v = tid; v < V; v += ROW_THREADS) s += expf(row[v] - mx);
+    }
     s = group_sum<64>(s);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -316,10 +334,18 @@ ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ ans
     const float lse = bc;
     int ans = (int)answers[b];
     ans = ans < 0 ? 0 : (ans >= V ? V - 1 : ans);
-    for (int v = tid; v < Vp; v += ROW_THREADS) {
-        float g = 0.f;
-        if (v < V) g = (expf(row[v] - lse) - (v == ans ? 1.0f : 0.0f)) * inv_b;
-        dlogits[(long)b * Vp + v] = g;
+    if (inreg) {
+#pragma unroll
+        for (int k = 0; k < CE_MAX_PER_THREAD; ++k) {
+            const int v = tid + k * ROW_THREADS;
+            if (v < Vp) dlogits[(long)b * Vp + v] = v < V ? (expf(x[k] - lse) - (v == ans ? 1.0f : 0.0f)) * inv_b : 0.f;
+        }
+    } else {
+        for (int v = tid; v < Vp; v += ROW_THREADS) {
+            float g = 0.f;
+            if (v < V) g = (expf(row[v] - lse) - (v == ans ? 1.0f : 0.0f)) * inv_b;
+            dlogits[(long)b * Vp + v] = g;
+        }
     }
     if (tid == 0) loss_rows[b] = lse - row[ans];
 }
@@ -357,7 +383,7 @@ dlast_kernel(const float* __restrict__ slabs, int nsplit, long slab_stride, int 
 // (padding_idx = 0 suppresses only the lookup gradient, src/model/_abstract_model.py:10).  The dense
 // logits-path dE is already in place; rows are added with full-row (>= 64 B contiguous) f32 atomics.
 // =============================================================================================
-#define SCATTER_FLOATS 16384          // LDS row accumulators per block: chunk = 16384 / (4*LPR) tokens
+#define SCATTER_FLOATS 8192           // LDS row accumulators per block: chunk = 8192 / (4*LPR) tokens
 template <int LPR>
 __global__ void __launch_bounds__(ROW_THREADS)
 embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, int B, int L, int d,
@@ -372,11 +398,12 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
     if ((int)blockIdx.x < scatter_blocks) {
         // Popular items (Zipf) would serialise hundreds of global float atomics on one row.  Each block
         // owns CHUNK tokens: every token finds the first occurrence of its id in the chunk (its leader),
-        // duplicates are folded into the leader's row with LDS atomics, and each leader then issues ONE
+        // all rows are folded into the leader's LDS row with LDS atomics, and each leader then issues ONE
         // global atomic row add (>= 64 B contiguous per row).
         const int T = B * L, t0 = blockIdx.x * CHUNK;
         const int n = min(CHUNK, T - t0);
         for (int i = threadIdx.x; i < CHUNK; i += ROW_THREADS) sid[i] = i < n ? ids32[t0 + i] : 0;
+        for (int i = threadIdx.x; i < SCATTER_FLOATS / 4; i += ROW_THREADS) st4(acc + 4 * i, f32x4{0, 0, 0, 0});
         __syncthreads();
         for (int j = threadIdx.x; j < CHUNK; j += ROW_THREADS) {
             const int id = sid[j];
@@ -385,31 +412,49 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
             lead[j] = l;
         }
         __syncthreads();
-        for (int j = lr; j < n; j += RPP)                 // leaders deposit their own row
-            if (colok && sid[j] != 0 && lead[j] == j) st4(acc + j * W + lc, ld4(de + (long)(t0 + j) * d + lc));
-        __syncthreads();
-        for (int j = lr; j < n; j += RPP)                 // duplicates fold into the leader's row
-            if (colok && sid[j] != 0 && lead[j] != j) {
-                const f32x4 g = ld4(de + (long)(t0 + j) * d + lc);
+        constexpr int NP = CHUNK / RPP;                   // rows per thread group, loads issued together
+        f32x4 g[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j = lr + p * RPP;
+            g[p] = f32x4{0, 0, 0, 0};
+            if (colok && j < n && sid[j] != 0) g[p] = ld4(de + (long)(t0 + j) * d + lc);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j = lr + p * RPP;
+            if (colok && j < n && sid[j] != 0) {          // padding_idx = 0: no lookup gradient for id 0
                 float* a = acc + lead[j] * W + lc;
-                atomicAdd(a + 0, g.x); atomicAdd(a + 1, g.y); atomicAdd(a + 2, g.z); atomicAdd(a + 3, g.w);
+                atomicAdd(a + 0, g[p].x); atomicAdd(a + 1, g[p].y); atomicAdd(a + 2, g[p].z); atomicAdd(a + 3, g[p].w);
             }
+        }
         __syncthreads();
-        for (int j = lr; j < n; j += RPP)
-            if (colok && sid[j] != 0 && lead[j] == j) {   // padding_idx = 0: no lookup gradient for id 0
-                const f32x4 g = ld4(acc + j * W + lc);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j = lr + p * RPP;
+            if (colok && j < n && sid[j] != 0 && lead[j] == j) {
+                const f32x4 r = ld4(acc + j * W + lc);
                 float* dst = dE + (long)sid[j] * d + lc;
-                unsafeAtomicAdd(dst + 0, g.x); unsafeAtomicAdd(dst + 1, g.y);
-                unsafeAtomicAdd(dst + 2, g.z); unsafeAtomicAdd(dst + 3, g.w);
+                unsafeAtomicAdd(dst + 0, r.x); unsafeAtomicAdd(dst + 1, r.y);
+                unsafeAtomicAdd(dst + 2, r.z); unsafeAtomicAdd(dst + 3, r.w);
             }
+        }
         return;
     }
     float (*red)[W] = reinterpret_cast<float (*)[W]>(esm);
     const int t = blockIdx.x - scatter_blocks;       // one block per position
-    f32x4 s = {0, 0, 0, 0};
-    if (colok)
-        for (int b = lr; b < B; b += RPP) s += ld4(de + ((long)b * L + t) * d + lc);
-    st4(&red[lr][lc], s);
+    f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+    if (colok) {
+        int bb = lr;
+        for (; bb + 3 * RPP < B; bb += 4 * RPP) {
+            s0 += ld4(de + ((long)bb * L + t) * d + lc);
+            s1 += ld4(de + ((long)(bb + RPP) * L + t) * d + lc);
+            s2 += ld4(de + ((long)(bb + 2 * RPP) * L + t) * d + lc);
+            s3 += ld4(de + ((long)(bb + 3 * RPP) * L + t) * d + lc);
+        }
+        for (; bb < B; bb += RPP) s0 += ld4(de + ((long)bb * L + t) * d + lc);
+    }
+    st4(&red[lr][lc], (s0 + s1) + (s2 + s3));
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += ROW_THREADS) {
         float a = 0.f;
@@ -426,27 +471,55 @@ struct ReduceJob { const float* src; float* dst; int nsplit; int len; long strid
 
 __global__ void __launch_bounds__(ROW_THREADS)
 multi_reduce_kernel(const ReduceJob* __restrict__ jobs) {
+    __shared__ float red[4][64];
     const ReduceJob j = jobs[blockIdx.y];
-    const int i = blockIdx.x * ROW_THREADS + threadIdx.x;
-    if (i >= j.len) return;
-    float a[8];
+    const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;       // element within the block, split group
+    const int i = blockIdx.x * 64 + e;
+    if (blockIdx.x * 64 >= j.len) return;
+    float a[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] = 0.f;
-    const float* p = j.src + i;
-    int s = 0;
-    for (; s + 7 < j.nsplit; s += 8) {
+    for (int k = 0; k < 16; ++k) a[k] = 0.f;
+    if (i < j.len) {
+        const float* p = j.src + i;
+        int s = sg;
+        for (; s + 60 < j.nsplit; s += 64) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] += p[(long)(s + k) * j.stride];
+            for (int k = 0; k < 16; ++k) a[k] += p[(long)(s + 4 * k) * j.stride];
+        }
+        for (int k = 0; s < j.nsplit; s += 4, ++k) a[k & 15] += p[(long)s * j.stride];
     }
-    for (; s < j.nsplit; ++s) a[0] += p[(long)s * j.stride];
-    j.dst[i] = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) * j.scale;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += a[k];
+    red[sg][e] = t;
+    __syncthreads();
+    if (sg == 0 && i < j.len) j.dst[i] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * j.scale;
 }
 
 // =============================================================================================
 // device-resident step state (lets a captured hipGraph replay with fresh dropout masks / Adam t):
 //   u64 state[0] = seed, [1] = forward-step counter, [2] = Adam t; f32 view of [3] = {lr/bc1, sqrt(bc2)}
 // =============================================================================================
-__global__ void step_begin_kernel(uint64_t* state) { state[1] += 1; }
+__global__ void step_begin_kernel(uint64_t* state, long long* cursor, int advance) {
+    state[1] += 1;
+    if (cursor) *cursor += advance;       // batch cursor of the device-resident sample table
+}
+
+// batch assembly on the device: ids[b,:] = table[perm[cursor + b], :], answers[b] = ans_table[perm[cursor + b]]
+// (replaces RandomSampler + DataLoader collation, src/dataset.py:207-211)
+__global__ void __launch_bounds__(ROW_THREADS)
+gather_batch_kernel(const int64_t* __restrict__ table, const int64_t* __restrict__ ans_table,
+                    const int64_t* __restrict__ perm, long n, const long long* __restrict__ cursor, int B, int L,
+                    int64_t* __restrict__ ids, int64_t* __restrict__ ans) {
+    const long base = *cursor;
+    for (int i = blockIdx.x * ROW_THREADS + threadIdx.x; i < B * L; i += gridDim.x * ROW_THREADS) {
+        const int b = i / L, t = i % L;
+        long src = base + b;
+        src = src < n ? perm[src] : 0;
+        ids[i] = table[src * L + t];
+        if (t == 0) ans[b] = ans_table[src];
+    }
+}
 
 __global__ void adam_tick_kernel(uint64_t* state, double lr, double b1, double b2) {
     const uint64_t t = state[2] + 1;

@@ -122,6 +122,22 @@ class DeviceBatches:
     def set_epoch(self, epoch: int):
         self.epoch = epoch
 
+    def local_permutation(self) -> torch.Tensor:
+        """This epoch's sample order as seen by this rank: consecutive runs of batch_size entries are the
+        rank's slice of consecutive global batches (all of the epoch's samples when world == 1)."""
+        n = self.answers.shape[0]
+        if self.shuffle:
+            gen = torch.Generator(device="cpu")
+            gen.manual_seed(self.seed + self.epoch)
+            perm = torch.randperm(n, generator=gen).to(self.device)
+        else:
+            perm = torch.arange(n, device=self.device)
+        if self.world > 1:
+            g = self.batch_size * self.world
+            nb = n // g
+            perm = perm[:nb * g].view(nb, self.world, self.batch_size)[:, self.rank, :].reshape(-1)
+        return perm.contiguous()
+
     def __iter__(self):
         n = self.answers.shape[0]
         if self.shuffle:

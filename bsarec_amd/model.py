@@ -319,6 +319,25 @@ class BSARecModel(nn.Module):
         plan._ids_keepalive, plan._ans_keepalive = ids, ans
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
+    def train_step_indexed(self, table, answers_table, perm, cursor, batch: int) -> torch.Tensor:
+        """train_step fed from a device-resident sample table: the batch perm[cursor : cursor+batch] is gathered
+        on the device and the cursor advanced by the same C call, so a captured graph replays a whole epoch
+        without any host-side tensor work."""
+        if self._adam is None:
+            raise RuntimeError("call configure_adam() first")
+        plan = self._plan(batch)
+        if not hasattr(plan, "ids_buf"):
+            dev = self._arena.device
+            plan.ids_buf = torch.zeros((batch, self.args.max_seq_length), dtype=torch.int64, device=dev)
+            plan.ans_buf = torch.zeros((batch,), dtype=torch.int64, device=dev)
+        a = self._adam
+        L.check(plan.lib.bsarec_train_step_indexed(
+            plan.handle, table.data_ptr(), answers_table.data_ptr(), perm.data_ptr(), perm.shape[0], cursor.data_ptr(),
+            plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), self._arena.data_ptr(), self._garena.data_ptr(),
+            a["m"].data_ptr(), a["v"].data_ptr(), self._numel, a["lr"], a["b1"], a["b2"], a["eps"], a["wd"],
+            self._stream()), "bsarec_train_step_indexed")
+        return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
     def adam_step(self, grad_scale: float = 1.0):
         """Fused Adam over the flat arenas (after an external gradient all-reduce)."""
         a = self._adam

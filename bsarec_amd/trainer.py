@@ -14,6 +14,7 @@ from typing import Optional
 import numpy as np
 import torch
 
+from .data import DeviceBatches
 from .dp import allreduce_sum_
 from .model import BSARecModel
 
@@ -130,7 +131,79 @@ class Trainer:
         graph.replay()
         return loss
 
+    def _epoch_indexed(self, dl: DeviceBatches):
+        """One epoch straight off the device-resident sample table: per step ONE C call (gather + forward +
+        loss + backward + Adam), replayed from a hipGraph when single-GPU; no per-step host tensor work."""
+        m, B = self.model, dl.batch_size
+        perm = dl.local_permutation()
+        dl.epoch += 1
+        n = perm.shape[0]
+        nfull, tail = n // B, n % B
+        if not hasattr(self, "_cursor"):
+            self._cursor = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._loss_sum = torch.zeros((), dtype=torch.float32, device=self.device)
+            self._perm_buf = torch.zeros(dl.answers.shape[0], dtype=torch.int64, device=self.device)
+        self._perm_buf[:n].copy_(perm)
+        pbuf = self._perm_buf[:n]
+        self._cursor.zero_()
+        self._loss_sum.zero_()
+
+        def body():
+            if self.world == 1:
+                loss = m.train_step_indexed(dl.inputs, dl.answers, pbuf, self._cursor, B)
+            else:
+                plan = m._plan(B)
+                if not hasattr(plan, "ids_buf"):
+                    plan.ids_buf = torch.zeros((B, self.args.max_seq_length), dtype=torch.int64, device=self.device)
+                    plan.ans_buf = torch.zeros((B,), dtype=torch.int64, device=self.device)
+                from . import _lib as L
+                L.check(plan.lib.bsarec_gather_batch(dl.inputs.data_ptr(), dl.answers.data_ptr(), pbuf.data_ptr(), n,
+                                                     self._cursor.data_ptr(), B, self.args.max_seq_length,
+                                                     plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), m._stream()),
+                        "bsarec_gather_batch")
+                self._cursor += B
+                loss = self._step_eager(plan.ids_buf, plan.ans_buf)
+            self._loss_sum += loss
+
+        if nfull:
+            if self.use_graph:
+                key = ("indexed", B, n)
+                if key not in self._graphs:
+                    m._plan(B)
+                    body()                                  # eager first step also creates the static buffers
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        body()
+                    self._graphs[key] = graph
+                    done = 1
+                else:
+                    done = 0
+                graph = self._graphs[key]
+                for _ in range(nfull - done):
+                    graph.replay()
+            else:
+                for _ in range(nfull):
+                    body()
+        nb = nfull
+        if tail:                                            # short last batch (single GPU only): its own plan, eager
+            idx = perm[nfull * B:]
+            self._loss_sum += self._step_eager(dl.inputs[idx], dl.answers[idx])
+            nb += 1
+        return self._loss_sum, nb
+
     def iteration(self, epoch, dataloader, train=True):
+        if train and isinstance(dataloader, DeviceBatches):
+            self.model.train()
+            loss_sum, nb = self._epoch_indexed(dataloader)
+            rec = loss_sum.item() / max(nb, 1)
+            if self.world > 1:
+                t = torch.tensor([rec], device=self.device)
+                torch.distributed.all_reduce(t, group=self.pg)
+                rec = t.item() / self.world
+            post_fix = {"epoch": epoch, "rec_loss": '{:.4f}'.format(rec)}
+            if (epoch + 1) % getattr(self.args, "log_freq", 1) == 0:
+                self.logger.info(str(post_fix))
+            return post_fix
         if train:
             self.model.train()
             loss_sum = torch.zeros((), dtype=torch.float32, device=self.device)

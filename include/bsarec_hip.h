@@ -129,6 +129,19 @@ int bsarec_train_step(bsarec_plan_t *plan, const int64_t *ids, const int64_t *an
                       const float *grads_flat, float *exp_avg, float *exp_avg_sq, long n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, void *stream);
 
+/* Device-side batch assembly from a resident sample table (replaces RandomSampler + DataLoader collation,
+ * src/dataset.py:207-211): ids_out[b,:] = table[perm[*cursor + b], :], answers_out[b] = answers_table[perm[*cursor + b]].
+ * `cursor` is one int64 on the device. */
+int bsarec_gather_batch(const int64_t *table, const int64_t *answers_table, const int64_t *perm, long n_samples,
+                        const void *cursor, int B, int L, int64_t *ids_out, int64_t *answers_out, void *stream);
+
+/* bsarec_train_step fed from the resident table: gather the batch at *cursor, advance *cursor by B, then
+ * forward + loss + backward + Adam.  A captured graph of this call replays a whole epoch with no host work. */
+int bsarec_train_step_indexed(bsarec_plan_t *plan, const int64_t *table, const int64_t *answers_table,
+                              const int64_t *perm, long n_samples, void *cursor, int64_t *ids_buf, int64_t *answers_buf,
+                              float *params_flat, const float *grads_flat, float *exp_avg, float *exp_avg_sq, long n,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
+
 /* Stand-alone FrequencyLayer (src/model/bsarec.py:90-104) for per-op parity tests:
  * y = LN(Drop(low + beta^2 (x - low)) + x); backward given dy. */
 int bsarec_freq_layer_fwd(const float *x, const float *sqrt_beta, const float *ln_w, const float *ln_b,
