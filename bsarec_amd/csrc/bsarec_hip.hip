@@ -111,7 +111,7 @@ struct bsarec_plan {
     float *logits, *dlogits, *loss_rows, *loss;
     // backward scratch (shared by all layers)
     float *dXa, *dXb, *dz, *dT, *dU, *dH, *dXacc, *dO, *dF, *dC, *dS, *dq, *dk, *dv, *dXtmp, *dlast_slab;
-    float *slab_w, *slab_b, *part_ln, *part_beta;
+    float *slab_w, *slab_b, *part_ln, *part_beta, *trash;
     ReduceJob* jobs; int jobs_per_layer;
 };
 
@@ -193,6 +193,7 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     p.slab_b = cv.take<float>((long)p.nsplit * 9 * d);           // bq bk bv bo (d) + b1 (4d) + b2 (d)
     p.part_ln = cv.take<float>((long)p.nblk * 6 * d);            // gamma/beta partials of the 3 LayerNorms
     p.part_beta = cv.take<float>(B * d);
+    p.trash = cv.take<float>(1024);
     *total = cv.off;
 }
 
@@ -390,6 +391,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    F.trash = p.trash;
     F.stamps = g_stamps ? g_stamps + 32 * (2 * l) : nullptr;
     const size_t smem = fused_fwd_smem_bytes();
 #define FUSED_FWD_CASE(DHV) { \
@@ -397,7 +399,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
         if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
         ProfScope prof(BSAREC_K_FUSED_FWD, s); \
-        LAUNCH(fused_layer_fwd_kernel<DHV>, dim3(c.batch), dim3(256), smem, s, F); }
+        LAUNCH(fused_layer_fwd_kernel<DHV>, dim3(c.batch), dim3(512), smem, s, F); }
     if (p.dh == 16) FUSED_FWD_CASE(16) else if (p.dh == 32) FUSED_FWD_CASE(32) else FUSED_FWD_CASE(64)
 #undef FUSED_FWD_CASE
     return (int)hipGetLastError();
@@ -424,6 +426,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha);
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    F.trash = p.trash;
     F.stamps = g_stamps ? g_stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = fused_bwd_smem_bytes();
 #define FUSED_BWD_CASE(DHV) { \

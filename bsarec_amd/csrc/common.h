@@ -40,8 +40,9 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 __device__ __forceinline__ f32x4 drop_mult4(const DropP& d, uint64_t grp) {
     f32x4 m = {d.scale, d.scale, d.scale, d.scale};
     if (d.thresh == 0) return m;
-    const uint64_t seed = d.rng[0];
-    const uint4 w = philox4x32_10((uint32_t)grp, (uint32_t)(grp >> 32), d.site, (uint32_t)d.rng[1],
+    const __attribute__((address_space(1))) uint64_t* rng = (const __attribute__((address_space(1))) uint64_t*)d.rng;
+    const uint64_t seed = rng[0];
+    const uint4 w = philox4x32_10((uint32_t)grp, (uint32_t)(grp >> 32), d.site, (uint32_t)rng[1],
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
     m.x = w.x >= d.thresh ? d.scale : 0.f;
     m.y = w.y >= d.thresh ? d.scale : 0.f;

@@ -14,6 +14,7 @@
 #pragma once
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 #define FS 68          // LDS row stride (floats) of a 64-wide tile: 16-B aligned rows, conflict-free b128 reads
 #define FU 260         // LDS row stride of the 256-wide FFN tile
@@ -27,6 +28,7 @@ struct FusedFwdP {
     int L, Lp, cb, heads;
     float alpha, oma, eps;
     DropP drop_f, drop_p, drop_o, drop_ff;
+    float* trash;           // >= 1 KiB scratch: target of the stores of padded rows (keeps the store stream branch-free)
     long long* stamps;      // diagnostic: per-phase s_memtime of workgroup 0 (null in production)
 };
 
@@ -55,6 +57,27 @@ __device__ __forceinline__ T kernarg_field(unsigned byte_off) {
 #define KARG(S, f) kernarg_field<decltype(S::f)>((unsigned)offsetof(S, f))
 #define STAMP(i) do { long long* st_ = KARG(PTYPE, stamps); if (st_ && blockIdx.x == 0 && threadIdx.x == 0) st_[i] = clock64(); } while (0)
 
+
+// Explicit global-address-space accessors.  Pointers read from the kernarg block at run time are generic to
+// the compiler, and generic accesses become flat_load / flat_store, which tick BOTH vmcnt and lgkmcnt: every LDS
+// wait would then also wait for the global stores in flight.  Casting at the access site keeps them global_*.
+#define AS_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ f32x4 gld4(const float* p) { return *reinterpret_cast<const AS_GLOBAL f32x4*>((const AS_GLOBAL float*)p); }
+__device__ __forceinline__ void gst4(float* p, f32x4 v) { *reinterpret_cast<AS_GLOBAL f32x4*>((AS_GLOBAL float*)p) = v; }
+__device__ __forceinline__ float gld(const float* p) { return *(const AS_GLOBAL float*)p; }
+__device__ __forceinline__ void gst(float* p, float v) { *(AS_GLOBAL float*)p = v; }
+__device__ __forceinline__ int gldi(const int* p) { return *(const AS_GLOBAL int*)p; }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every global store
+// still in flight (the activations saved for backward) would have to be acknowledged at each of the ~10 phase
+// boundaries.  Nothing written to global memory in these kernels is read back inside them, so only the LDS
+// counter has to drain before the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // acc += A(rows from LDS) . W^T(rows from global), K = 8*NKB.  sa / gw already point at this lane's row + 4*half.
@@ -74,10 +97,10 @@ __device__ __forceinline__ void mma_rows_w(const float* __restrict__ sa, const f
 
 // ---- pruned DFT with a per-workgroup twiddle table tab[k][t] = (cos, sin)(2 pi k t / L), k < cb, t < 64
 __device__ __forceinline__ void build_twiddle_table(const float* __restrict__ tw, int L, int cb, float* __restrict__ tab) {
-    for (int i = threadIdx.x; i < cb * 64; i += 256) {
+    for (int i = threadIdx.x; i < cb * 64; i += blockDim.x) {
         const int k = i >> 6, t = i & 63;
         float c = 0.f, s = 0.f;
-        if (t < L) { const int a = (int)((unsigned)(k * t) % (unsigned)L); c = tw[2 * a]; s = tw[2 * a + 1]; }
+        if (t < L) { const int a = (int)((unsigned)(k * t) % (unsigned)L); c = gld(tw + 2 * a); s = gld(tw + 2 * a + 1); }
         tab[2 * i] = c; tab[2 * i + 1] = s;
     }
 }
@@ -117,7 +140,7 @@ __device__ __forceinline__ void dft_spectrum_tab(const Src& src, int L, int cb, 
                 st4(part + (((lr * NSRC + s) * 4 + j) * 2 + 0) * 64 + lc, re[s][j]);
                 st4(part + (((lr * NSRC + s) * 4 + j) * 2 + 1) * 64 + lc, im[s][j]);
             }
-        __syncthreads();
+        lds_barrier();
         for (int i = threadIdx.x; i < NSRC * 4 * 128; i += 256) {
             const int s = i / 512, j = (i >> 7) & 3, rc = i & 127;
             if (k0 + j < cb) {
@@ -127,7 +150,7 @@ __device__ __forceinline__ void dft_spectrum_tab(const Src& src, int L, int cb, 
                 spec[(s * cb + k0 + j) * 128 + rc] = acc;
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -145,7 +168,7 @@ __device__ __forceinline__ f32x4 lowpass_tab(const float* __restrict__ spec, int
 // weight fragments: issue the loads of a whole 64-deep K chunk, use them later (latency hidden by the caller)
 __device__ __forceinline__ void load_w8(const float* __restrict__ gw, f32x4 (&w)[8]) {
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) w[kb] = ld4(gw + 8 * kb);
+    for (int kb = 0; kb < 8; ++kb) w[kb] = gld4(gw + 8 * kb);
 }
 __device__ __forceinline__ void mma_w8(const float* __restrict__ sa, const f32x4 (&w)[8], f32x16& acc) {
 #pragma unroll
@@ -159,29 +182,30 @@ template <int LDW>
 __device__ __forceinline__ void load_wT8(const float* __restrict__ gw, f32x4 (&w)[8]) {
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        w[kb].x = gw[(8 * kb + 0) * LDW]; w[kb].y = gw[(8 * kb + 1) * LDW];
-        w[kb].z = gw[(8 * kb + 2) * LDW]; w[kb].w = gw[(8 * kb + 3) * LDW];
+        w[kb].x = gld(gw + (8 * kb + 0) * LDW); w[kb].y = gld(gw + (8 * kb + 1) * LDW);
+        w[kb].z = gld(gw + (8 * kb + 2) * LDW); w[kb].w = gld(gw + (8 * kb + 3) * LDW);
     }
 }
 
-// LayerNorm row pass over a 64 x 64 LDS tile (16 lanes x float4 per row, 16 rows per pass):
-//   v = (tile + bias) * dropout + residual ; xhat, rstd -> global ; y = gamma*xhat + beta
-//   MIX: y = alpha*dsp + (1-alpha)*y.  Result -> LDS (outL, may be null) and global (outG).
+// LayerNorm row pass over a 64 x 64 LDS tile held as two split-K partial tiles (16 lanes x float4 per row,
+// blockDim/16 rows per pass):  v = (tileA + tileB + bias) * dropout + residual ; xhat, rstd -> global ;
+// y = gamma*xhat + beta ; MIX: y = alpha*dsp + (1-alpha)*y.  Result -> LDS (outL, may be null) and global (outG).
 template <bool MIX>
-__device__ __forceinline__ void ln_rows_64(const float* __restrict__ tile, const float* __restrict__ bias,
-                                           const float* __restrict__ resid, const DropP& drop, const float* __restrict__ gamma,
+__device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, const float* __restrict__ tileB,
+                                           const float* __restrict__ bias, const float* __restrict__ resid,
+                                           const DropP& drop, const float* __restrict__ gamma,
                                            const float* __restrict__ beta, float eps, const float* __restrict__ dsp,
                                            float alpha, float oma, long tok0, int L, float* __restrict__ outL,
                                            float* __restrict__ outG, float* __restrict__ xhatG, float* __restrict__ rstdG) {
     const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
-    const f32x4 bi = ld4(bias + lc), g = ld4(gamma + lc), be = ld4(beta + lc);
-#pragma unroll
-    for (int r0 = 0; r0 < 64; r0 += 16) {
-        const int r = r0 + lr;
+    const int rpp = blockDim.x >> 4;
+    const f32x4 bi = gld4(bias + lc), g = gld4(gamma + lc), be = gld4(beta + lc);
+    for (int r = lr; r < 64; r += rpp) {
         const bool ok = r < L;
         const long e = (tok0 + r) * 64 + lc;
         f32x4 v = {0, 0, 0, 0};
-        if (ok) v = (ld4(tile + r * FS + lc) + bi) * drop_mult4(drop, (uint64_t)e >> 2) + ld4(resid + r * FS + lc);
+        if (ok) v = (ld4(tileA + r * FS + lc) + ld4(tileB + r * FS + lc) + bi) * drop_mult4(drop, (uint64_t)e >> 2) +
+                    ld4(resid + r * FS + lc);
         const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
         f32x4 dl = {0, 0, 0, 0};
         if (ok) dl = v - mean;
@@ -192,376 +216,421 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tile, const
             const f32x4 xh = dl * rs;
             y = g * xh + be;
             if (MIX) y = alpha * ld4(dsp + r * FS + lc) + oma * y;
-            st4(xhatG + e, xh);
-            st4(outG + e, y);
-            if (lc == 0) rstdG[tok0 + r] = rs;
+            gst4(xhatG + e, xh);
+            gst4(outG + e, y);
+            if (lc == 0) gst(rstdG + tok0 + r, rs);
         }
         if (outL) st4(outL + r * FS + lc, y);
     }
 }
 
+// 4-deep (K = 32) versions of the weight fragment helpers, for products whose K is split across wave groups
+__device__ __forceinline__ void load_w4(const float* __restrict__ gw, f32x4 (&w)[4]) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) w[kb] = gld4(gw + 8 * kb);
+}
+__device__ __forceinline__ void mma_w4(const float* __restrict__ sa, const f32x4 (&w)[4], f32x16& acc) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const f32x4 a = ld4(sa + 8 * kb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
+    }
+}
+
+// Forward: 8 waves = 2 groups of 4 (each group tiles 64 tokens x 64 features as 2 x 2 waves), two waves per SIMD
+// so that one wave's MFMA chain overlaps the other's VALU / memory waits:
+//   * FrequencyLayer (group 0, VALU + LDS) runs concurrently with the Q, K, V projections (group 1, MFMA);
+//   * attention: wave pair (2c, 2c+1) owns combo c = (head, query tile) and splits its two key tiles;
+//     row max / sum are exchanged through LDS, the two partial contexts are summed in a row pass;
+//   * dense and dense_2 split K across the groups (two partial tiles, summed by the LayerNorm row pass),
+//     dense_1 splits its four 64-wide output blocks.
 template <int DH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 #define PTYPE FusedFwdP
     const auto R0_L = KARG(FusedFwdP, L);
     const auto R0_Lp = KARG(FusedFwdP, Lp);
+    const auto R0_cb = KARG(FusedFwdP, cb);
     const auto R0_heads = KARG(FusedFwdP, heads);
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TS = 64 * FS;
     float* sX = sm;
-    float* sD = sX + 64 * FS;
-    float* sH = sD + 64 * FS;
-    float* sR = sH + 64 * FS;                   // union: {sQ, sK, sVt, sC} | sU | DFT partials
+    float* sD = sm + TS;
+    float* sH = sm + 2 * TS;                    // hmix; before that: DFT partials (with sE)
+    float* sE = sm + 3 * TS;                    // second partial tile
+    float* sR = sm + 4 * TS;                    // union: {sQ, sK, sVt, sC} | sU
     float* sQ = sR;
-    float* sK = sR + 64 * FS;
-    float* sVt = sR + 2 * 64 * FS;              // V transposed: [feature][token]
-    float* sC = sR + 3 * 64 * FS;
+    float* sK = sR + TS;
+    float* sVt = sR + 2 * TS;                   // V transposed: [feature][token]
+    float* sC = sR + 3 * TS;
     float* sU = sR;                             // [64][FU]
-    float* sTab = sR + 4 * 64 * FS;             // FUSED_MAX_CB * 64 * 2
+    float* sTab = sR + 4 * TS;                  // FUSED_MAX_CB * 64 * 2
     float* sSpec = sTab + FUSED_MAX_CB * 128;   // FUSED_MAX_CB * 2 * 64
-    int* sIds = reinterpret_cast<int*>(sSpec + FUSED_MAX_CB * 128);   // 64
+    float* sRed = sSpec + FUSED_MAX_CB * 128;   // softmax exchange: [4 pairs][2 key tiles][64 lanes]
+    int* sIds = reinterpret_cast<int*>(sRed + 512);   // 64
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int L = R0_L, Lp = R0_Lp, heads = R0_heads;
+    const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int L = R0_L, Lp = R0_Lp, heads = R0_heads, cb = R0_cb;
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;              // this lane's output feature inside a 64-wide block
     const long wrow = (long)col * 64 + 4 * half;
+    const int arow = (wm * 32 + l31) * FS + 4 * half;
+    float* const trash = KARG(FusedFwdP, trash) + 4 * lane;
 
     STAMP(0);
     const auto R1_X = KARG(FusedFwdP, X);
-    const auto R1_cb = KARG(FusedFwdP, cb);
     const auto R1_ids32 = KARG(FusedFwdP, ids32);
     const auto R1_tw = KARG(FusedFwdP, tw);
     const auto R1_wq = KARG(FusedFwdP, wq);
-    // weight fragments are fetched one product ahead of their use (L2 latency hides behind the previous phase)
     f32x4 wA[8], wB[8];
-    load_w8(R1_wq + wrow, wA);
+    if (grp == 1) load_w8(R1_wq + wrow, wA);
     // ---- phase 0: sequence tile, ids, twiddle table -> LDS
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+    for (int p = 0; p < 2; ++p) {
+        const int idx = tid + p * 512, r = idx >> 4, c4 = (idx & 15) << 2;
         f32x4 v = {0, 0, 0, 0};
-        if (r < L) v = ld4(R1_X + (tok0 + r) * 64 + c4);
+        if (r < L) v = gld4(R1_X + (tok0 + r) * 64 + c4);
         st4(sX + r * FS + c4, v);
     }
-    if (tid < 64) sIds[tid] = tid < L ? R1_ids32[tok0 + tid] : 0;
-    build_twiddle_table(R1_tw, L, R1_cb, sTab);
-    __syncthreads();
+    if (tid < 64) sIds[tid] = tid < L ? gldi(R1_ids32 + (tok0 + tid)) : 0;
+    build_twiddle_table(R1_tw, L, cb, sTab);
+    lds_barrier();
 
     STAMP(1);
-    const auto R2_cb = KARG(FusedFwdP, cb);
+    const auto R2_bk = KARG(FusedFwdP, bk);
+    const auto R2_bq = KARG(FusedFwdP, bq);
+    const auto R2_bv = KARG(FusedFwdP, bv);
     const auto R2_drop_f = KARG(FusedFwdP, drop_f);
     const auto R2_dsp = KARG(FusedFwdP, dsp);
     const auto R2_eps = KARG(FusedFwdP, eps);
     const auto R2_f_b = KARG(FusedFwdP, f_b);
     const auto R2_f_g = KARG(FusedFwdP, f_g);
+    const auto R2_k = KARG(FusedFwdP, k);
+    const auto R2_q = KARG(FusedFwdP, q);
     const auto R2_rstd_f = KARG(FusedFwdP, rstd_f);
     const auto R2_sqrt_beta = KARG(FusedFwdP, sqrt_beta);
+    const auto R2_v = KARG(FusedFwdP, v);
+    const auto R2_wk = KARG(FusedFwdP, wk);
+    const auto R2_wo = KARG(FusedFwdP, wo);
+    const auto R2_wv = KARG(FusedFwdP, wv);
     const auto R2_xhat_f = KARG(FusedFwdP, xhat_f);
-    // ---- phase 1: FrequencyLayer -> sD (dsp), xhat_f, rstd_f                src/model/bsarec.py:90-104
+    // ---- phases 1 || 2: FrequencyLayer (group 0)  ||  Q, K, V projections (group 1)
     {
-        auto src = [&](int, int t, int c) { return ld4(sX + t * FS + c); };
-        dft_spectrum_tab<1>(src, L, R2_cb, sTab, sSpec, sR);
-        const int lr = tid >> 4, lc = (tid & 15) << 2;
-        f32x4 b2 = ld4(R2_sqrt_beta + lc);
-        b2 = b2 * b2;
-        const f32x4 g = ld4(R2_f_g + lc), be = ld4(R2_f_b + lc);
+        float* part = sH;                            // [16][4][2][64] = 8192 floats over sH + sE
+        const int lr = (tid & 255) >> 4, lc = (tid & 15) << 2;
+        auto qkv = [&](auto whichc) {                // group 1: one 32 x 32 tile of Q, K or V per wave
+            constexpr int which = decltype(whichc)::value;
+            f32x16 acc;
 #pragma unroll
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-            const int t = r0 + lr;
-            const bool ok = t < L;
-            const long e = (tok0 + t) * 64 + lc;
-            f32x4 v = {0, 0, 0, 0};
-            if (ok) {
-                const f32x4 xv = ld4(sX + t * FS + lc);
-                const f32x4 low = lowpass_tab(sSpec, t, lc, L, R2_cb, sTab);
-                v = (low + b2 * (xv - low)) * drop_mult4(R2_drop_f, (uint64_t)e >> 2) + xv;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* bp = which == 0 ? R2_bq : which == 1 ? R2_bk : R2_bv;
+            float* G = which == 0 ? R2_q : which == 1 ? R2_k : R2_v;
+            if (which == 0) { load_w8(R2_wk + wrow, wB); mma_w8(sX + arow, wA, acc); }
+            else if (which == 1) { load_w8(R2_wv + wrow, wA); mma_w8(sX + arow, wB, acc); }
+            else mma_w8(sX + arow, wA, acc);
+            const float bias = gld(bp + col);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + rho(r) + 4 * half;
+                const float val = acc[r] + bias;
+                if (which == 0) sQ[row * FS + col] = val;
+                else if (which == 1) sK[row * FS + col] = val;
+                else sVt[col * FS + row] = val;
+                gst(row < L ? G + (tok0 + row) * 64 + col : trash, val);
             }
-            const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
-            f32x4 dl = {0, 0, 0, 0};
-            if (ok) dl = v - mean;
-            const float var = group_sum<16>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * (1.0f / 64.0f);
-            const float rs = 1.0f / sqrtf(var + R2_eps);
-            f32x4 y = {0, 0, 0, 0};
-            if (ok) {
-                const f32x4 xh = dl * rs;
-                y = g * xh + be;
-                st4(R2_xhat_f + e, xh);
-                if (R2_dsp) st4(R2_dsp + e, y);
-                if (lc == 0) R2_rstd_f[tok0 + t] = rs;
+        };
+#pragma unroll
+        for (int ch = 0; ch < FUSED_MAX_CB / 4; ++ch) {
+            const int k0 = 4 * ch;
+            if (k0 >= cb) break;
+            if (grp == 0) {                          // accumulate 4 bins over this thread's rows
+                f32x4 re[4], im[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { re[j] = f32x4{0, 0, 0, 0}; im[j] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+                for (int r0 = 0; r0 < 64; r0 += 16) {
+                    const int t = r0 + lr;
+                    if (t < L) {
+                        const f32x4 x = ld4(sX + t * FS + lc);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (k0 + j < cb) {
+                                const float c = sTab[2 * ((k0 + j) * 64 + t)], sn = sTab[2 * ((k0 + j) * 64 + t) + 1];
+                                re[j] += x * c; im[j] -= x * sn;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    st4(part + ((lr * 4 + j) * 2 + 0) * 64 + lc, re[j]);
+                    st4(part + ((lr * 4 + j) * 2 + 1) * 64 + lc, im[j]);
+                }
+            } else if (ch == 0) qkv(std::integral_constant<int, 0>{});
+            lds_barrier();
+            if (grp == 0) {
+                for (int i = tid; i < 512; i += 256) {
+                    const int j = i >> 7, rc = i & 127;
+                    if (k0 + j < cb) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) acc += part[g * 512 + i];
+                        sSpec[(k0 + j) * 128 + rc] = acc;
+                    }
+                }
+            } else if (ch == 0) qkv(std::integral_constant<int, 1>{});
+            lds_barrier();
+        }
+        if (grp == 0) {                              // low-pass, beta^2 high-pass, dropout, residual, LayerNorm -> sD
+            f32x4 b2 = gld4(R2_sqrt_beta + lc);
+            b2 = b2 * b2;
+            const f32x4 g = gld4(R2_f_g + lc), be = gld4(R2_f_b + lc);
+#pragma unroll
+            for (int r0 = 0; r0 < 64; r0 += 16) {
+                const int t = r0 + lr;
+                const bool ok = t < L;
+                const long e = (tok0 + t) * 64 + lc;
+                f32x4 v = {0, 0, 0, 0};
+                if (ok) {
+                    const f32x4 xv = ld4(sX + t * FS + lc);
+                    const f32x4 low = lowpass_tab(sSpec, t, lc, L, cb, sTab);
+                    v = (low + b2 * (xv - low)) * drop_mult4(R2_drop_f, (uint64_t)e >> 2) + xv;
+                }
+                const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
+                f32x4 dl = {0, 0, 0, 0};
+                if (ok) dl = v - mean;
+                const float var = group_sum<16>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * (1.0f / 64.0f);
+                const float rs = 1.0f / sqrtf(var + R2_eps);
+                f32x4 y = {0, 0, 0, 0};
+                if (ok) {
+                    const f32x4 xh = dl * rs;
+                    y = g * xh + be;
+                    gst4(R2_xhat_f + e, xh);
+                    if (R2_dsp) gst4(R2_dsp + e, y);
+                    if (lc == 0) gst(R2_rstd_f + (tok0 + t), rs);
+                }
+                st4(sD + t * FS + lc, y);
             }
-            st4(sD + t * FS + lc, y);
+        } else {
+            qkv(std::integral_constant<int, 2>{});
         }
     }
-    __syncthreads();            // DFT partials (sR) are dead; sQ/sK/sVt may be written
-
-    STAMP(2);
-    const auto R3_bk = KARG(FusedFwdP, bk);
-    const auto R3_bq = KARG(FusedFwdP, bq);
-    const auto R3_bv = KARG(FusedFwdP, bv);
-    const auto R3_k = KARG(FusedFwdP, k);
-    const auto R3_q = KARG(FusedFwdP, q);
-    const auto R3_v = KARG(FusedFwdP, v);
-    const auto R3_wk = KARG(FusedFwdP, wk);
-    const auto R3_wo = KARG(FusedFwdP, wo);
-    const auto R3_wv = KARG(FusedFwdP, wv);
-    // ---- phase 2: Q, K, V projections                                     src/model/_modules.py:109-111
-    {
-        const float* sa = sX + (wm * 32 + l31) * FS + 4 * half;
-        f32x16 acc;
-        // Q
-        load_w8(R3_wk + wrow, wB);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w8(sa, wA, acc);
-        {
-            const float bias = R3_bq[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + rho(r) + 4 * half;
-                const float val = acc[r] + bias;
-                sQ[row * FS + col] = val;
-                if (row < L) R3_q[(tok0 + row) * 64 + col] = val;
-            }
-        }
-        // K
-        load_w8(R3_wv + wrow, wA);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w8(sa, wB, acc);
-        {
-            const float bias = R3_bk[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + rho(r) + 4 * half;
-                const float val = acc[r] + bias;
-                sK[row * FS + col] = val;
-                if (row < L) R3_k[(tok0 + row) * 64 + col] = val;
-            }
-        }
-        // V (kept transposed in LDS)
-        load_w8(R3_wo + wrow, wB);                           // dense weights for phase 4, held across the attention
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w8(sa, wA, acc);
-        {
-            const float bias = R3_bv[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + rho(r) + 4 * half;
-                const float val = acc[r] + bias;
-                sVt[col * FS + row] = val;
-                if (row < L) R3_v[(tok0 + row) * 64 + col] = val;
-            }
-        }
-    }
-    __syncthreads();
+    // dense weights for phase 4 (this group's K half), held across the attention
+    f32x4 wO[4];
+    load_w4(R2_wo + wrow + 32 * grp, wO);
+    lds_barrier();
 
     STAMP(3);
-    const auto R4_ctx = KARG(FusedFwdP, ctx);
-    const auto R4_drop_p = KARG(FusedFwdP, drop_p);
-    const auto R4_probs = KARG(FusedFwdP, probs);
+    const auto R3_ctx = KARG(FusedFwdP, ctx);
+    const auto R3_drop_p = KARG(FusedFwdP, drop_p);
+    const auto R3_probs = KARG(FusedFwdP, probs);
     // ---- phase 3: attention, transposed: lane = query, registers = keys    src/model/_modules.py:118-135
     {
         const int nt = (L + 31) >> 5;                        // token tiles actually populated (1 or 2)
         const float sqrt_dh = sqrtf((float)DH);
         constexpr int NCT = (DH + 31) / 32;
-        for (int combo = wave; combo < heads * nt; combo += 4) {
-            const int head = combo / nt, qt = combo % nt;
+        const int ncombo = heads * nt;
+        const int pair = wave >> 1, kt = wave & 1;
+        for (int c0 = 0; c0 < ncombo; c0 += 4) {
+            const int combo = c0 + pair;
+            const bool act = combo < ncombo && kt < nt;
+            const int head = act ? combo / nt : 0, qt = act ? combo % nt : 0;
             const int query = 32 * qt + l31;
-            f32x16 st[2];
+            f32x16 st;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-                if (kt < nt) {
-                    const float* ka = sK + (32 * kt + l31) * FS + head * DH + 4 * half;
-                    const float* qb = sQ + query * FS + head * DH + 4 * half;
-#pragma unroll
-                    for (int kb = 0; kb < DH / 8; ++kb) {
-                        const f32x4 a = ld4(ka + 8 * kb), q4 = ld4(qb + 8 * kb);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            st[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], q4[s], st[kt], 0, 0, 0);
-                    }
-                }
-            }
-            // scale, mask (-10000, additive, fp32), softmax over keys
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
             float mx = -INFINITY;
+            if (act) {
+                const float* ka = sK + (32 * kt + l31) * FS + head * DH + 4 * half;
+                const float* qb = sQ + query * FS + head * DH + 4 * half;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kb = 0; kb < DH / 8; ++kb) {
+                    const f32x4 a = ld4(ka + 8 * kb), q4 = ld4(qb + 8 * kb);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], q4[s], st, 0, 0, 0);
+                }
+                // scale, mask (-10000, additive, fp32)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = 32 * kt + rho(r) + 4 * half;
                     float s = -INFINITY;
-                    if (key < L) s = st[kt][r] / sqrt_dh + ((key <= query && sIds[key] > 0) ? 0.0f : -10000.0f);
-                    st[kt][r] = s;
+                    if (key < L) s = st[r] / sqrt_dh + ((key <= query && sIds[key] > 0) ? 0.0f : -10000.0f);
+                    st[r] = s;
                     mx = fmaxf(mx, s);
                 }
-            mx = xor32_max(mx);
+                mx = xor32_max(mx);
+                sRed[(pair * 2 + kt) * 64 + lane] = mx;
+            }
+            lds_barrier();
             float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            if (act) {
+                if (nt == 2) mx = fmaxf(mx, sRed[(pair * 2 + (kt ^ 1)) * 64 + lane]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = 32 * kt + rho(r) + 4 * half;
-                    const float e = key < L ? __expf(st[kt][r] - mx) : 0.f;
-                    st[kt][r] = e;
+                    const float e = key < L ? __expf(st[r] - mx) : 0.f;
+                    st[r] = e;
                     sum += e;
                 }
-            sum = xor32_sum(sum);
-            const float inv = 1.0f / sum;
-            // probabilities -> global (16 B per lane), then dropout in place
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                sum = xor32_sum(sum);
+            }
+            lds_barrier();                                 // every partner has read the maxima
+            if (act) sRed[(pair * 2 + kt) * 64 + lane] = sum;
+            lds_barrier();
+            if (act) {
+                if (nt == 2) sum += sRed[(pair * 2 + (kt ^ 1)) * 64 + lane];
+                const float inv = 1.0f / sum;
+                // probabilities -> global (16 B per lane), then dropout in place
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int key0 = 32 * kt + 8 * g + 4 * half;
-                    f32x4 p = {st[kt][4 * g] * inv, st[kt][4 * g + 1] * inv, st[kt][4 * g + 2] * inv, st[kt][4 * g + 3] * inv};
+                    f32x4 p = {st[4 * g] * inv, st[4 * g + 1] * inv, st[4 * g + 2] * inv, st[4 * g + 3] * inv};
                     f32x4 m = {1.f, 1.f, 1.f, 1.f};
                     if (query < L && key0 < Lp) {
                         const long e = (((long)b * heads + head) * L + query) * Lp + key0;
-                        st4(R4_probs + e, p);
-                        m = drop_mult4(R4_drop_p, (uint64_t)e >> 2);
+                        gst4(R3_probs + e, p);
+                        m = drop_mult4(R3_drop_p, (uint64_t)e >> 2);
                     }
                     p = p * m;
-                    st[kt][4 * g] = p.x; st[kt][4 * g + 1] = p.y; st[kt][4 * g + 2] = p.z; st[kt][4 * g + 3] = p.w;
+                    st[4 * g] = p.x; st[4 * g + 1] = p.y; st[4 * g + 2] = p.z; st[4 * g + 3] = p.w;
                 }
-            // ctx^T = V^T . P^T   (P^T accumulators are the B operand as they stand)
+                // partial ctx^T over this wave's key tile  (P^T accumulators are the B operand as they stand)
+                float* dstT = kt == 0 ? sC : sE;
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                f32x16 cacc;
+                for (int ct = 0; ct < NCT; ++ct) {
+                    f32x16 cacc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
-                const bool crow_ok = 32 * ct + l31 < DH;
-                const float* va = sVt + (head * DH + 32 * ct + (crow_ok ? l31 : 0)) * FS + 4 * half;
+                    for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
+                    const bool crow_ok = 32 * ct + l31 < DH;
+                    const float* va = sVt + (head * DH + 32 * ct + (crow_ok ? l31 : 0)) * FS + 32 * kt + 4 * half;
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    if (kt < nt) {
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 a = ld4(va + 8 * g);
+                        if (!crow_ok) a = f32x4{0, 0, 0, 0};
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 a = ld4(va + 32 * kt + 8 * g);
-                            if (!crow_ok) a = f32x4{0, 0, 0, 0};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], st[kt][4 * g + j], cacc, 0, 0, 0);
-                        }
+                        for (int j = 0; j < 4; ++j)
+                            cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], st[4 * g + j], cacc, 0, 0, 0);
                     }
-                }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = 32 * ct + 8 * g + 4 * half;
-                    if (c < DH) {
-                        const f32x4 o = {cacc[4 * g], cacc[4 * g + 1], cacc[4 * g + 2], cacc[4 * g + 3]};
-                        st4(sC + query * FS + head * DH + c, o);
-                        if (query < L) st4(R4_ctx + (tok0 + query) * 64 + head * DH + c, o);
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = 32 * ct + 8 * g + 4 * half;
+                        if (c < DH)
+                            st4(dstT + query * FS + head * DH + c, f32x4{cacc[4 * g], cacc[4 * g + 1], cacc[4 * g + 2], cacc[4 * g + 3]});
                     }
                 }
             }
+            lds_barrier();                                 // sRed is reused by the next round of combos
         }
-        // token tiles that no combo covered (L <= 32): keep the context rows defined
-        if (nt == 1)
-            for (int idx = tid; idx < 32 * 16; idx += 256) st4(sC + (32 + (idx >> 4)) * FS + ((idx & 15) << 2), f32x4{0, 0, 0, 0});
+        // context = sum of the key-tile partials -> sC (rows >= 32*nt are zero) and global, 16 B per lane
+        {
+            const int lr = tid >> 4, lc = (tid & 15) << 2;
+#pragma unroll
+            for (int r0 = 0; r0 < 64; r0 += 32) {
+                const int r = r0 + lr;
+                f32x4 v = {0, 0, 0, 0};
+                if (r < 32 * nt) { v = ld4(sC + r * FS + lc); if (nt == 2) v += ld4(sE + r * FS + lc); }
+                st4(sC + r * FS + lc, v);
+                if (r < L) gst4(R3_ctx + (tok0 + r) * 64 + lc, v);
+            }
+        }
     }
-    __syncthreads();
+    lds_barrier();
 
     STAMP(4);
-    const auto R5_a_b = KARG(FusedFwdP, a_b);
-    const auto R5_a_g = KARG(FusedFwdP, a_g);
-    const auto R5_alpha = KARG(FusedFwdP, alpha);
-    const auto R5_bo = KARG(FusedFwdP, bo);
-    const auto R5_drop_o = KARG(FusedFwdP, drop_o);
-    const auto R5_eps = KARG(FusedFwdP, eps);
-    const auto R5_hmix = KARG(FusedFwdP, hmix);
-    const auto R5_oma = KARG(FusedFwdP, oma);
-    const auto R5_rstd_a = KARG(FusedFwdP, rstd_a);
-    const auto R5_w1 = KARG(FusedFwdP, w1);
-    const auto R5_xhat_a = KARG(FusedFwdP, xhat_a);
-    // ---- phase 4: dense + dropout + residual + LayerNorm + alpha mix   _modules.py:136-138, bsarec.py:78
+    const auto R4_a_b = KARG(FusedFwdP, a_b);
+    const auto R4_a_g = KARG(FusedFwdP, a_g);
+    const auto R4_alpha = KARG(FusedFwdP, alpha);
+    const auto R4_bo = KARG(FusedFwdP, bo);
+    const auto R4_drop_o = KARG(FusedFwdP, drop_o);
+    const auto R4_eps = KARG(FusedFwdP, eps);
+    const auto R4_hmix = KARG(FusedFwdP, hmix);
+    const auto R4_oma = KARG(FusedFwdP, oma);
+    const auto R4_rstd_a = KARG(FusedFwdP, rstd_a);
+    const auto R4_w1 = KARG(FusedFwdP, w1);
+    const auto R4_xhat_a = KARG(FusedFwdP, xhat_a);
+    // ---- phase 4: dense (K split across the groups) + dropout + residual + LayerNorm + alpha mix
     {
-        load_w8(R5_w1 + wrow, wA);                            // first dense_1 block, used in phase 5
+        load_w8(R4_w1 + (long)(128 * grp + col) * 64 + 4 * half, wA);      // first dense_1 block of this group
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w8(sC + (wm * 32 + l31) * FS + 4 * half, wB, acc);
+        mma_w4(sC + arow + 32 * grp, wO, acc);
+        float* part = grp == 0 ? sQ : sK;                                  // sQ / sK are dead: partial tiles
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sQ[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];      // sQ is dead: scratch tile
+        for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
-    __syncthreads();
-    ln_rows_64<true>(sQ, R5_bo, sX, R5_drop_o, R5_a_g, R5_a_b, R5_eps, sD, R5_alpha, R5_oma, tok0, L, sH, R5_hmix, R5_xhat_a, R5_rstd_a);
-    __syncthreads();
+    lds_barrier();
+    ln_rows_64<true>(sQ, sK, R4_bo, sX, R4_drop_o, R4_a_g, R4_a_b, R4_eps, sD, R4_alpha, R4_oma, tok0, L, sH, R4_hmix, R4_xhat_a,
+                     R4_rstd_a);
+    lds_barrier();
 
     STAMP(5);
-    const auto R6_b1 = KARG(FusedFwdP, b1);
-    const auto R6_u = KARG(FusedFwdP, u);
-    const auto R6_w1 = KARG(FusedFwdP, w1);
-    const auto R6_w2 = KARG(FusedFwdP, w2);
-    // ---- phase 5: dense_1 + erf-GELU -> sU (and pre-activation u -> global)       _modules.py:62-63
+    const auto R5_b1 = KARG(FusedFwdP, b1);
+    const auto R5_u = KARG(FusedFwdP, u);
+    const auto R5_w1 = KARG(FusedFwdP, w1);
+    const auto R5_w2 = KARG(FusedFwdP, w2);
+    // ---- phase 5: dense_1 + erf-GELU -> sU (and pre-activation u -> global): group g owns blocks 2g, 2g+1
     {
-        const float* sa = sH + (wm * 32 + l31) * FS + 4 * half;
+        const float* sa = sH + arow;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            const int c256 = blk * 64 + col;
-            f32x4 (&wcur)[8] = (blk & 1) ? wB : wA;
-            f32x4 (&wnxt)[8] = (blk & 1) ? wA : wB;
-            if (blk < 3) load_w8(R6_w1 + (long)(c256 + 64) * 64 + 4 * half, wnxt);
-            else load_w8(R6_w2 + (long)col * 256 + 4 * half, wnxt);              // first dense_2 chunk
+        for (int i = 0; i < 2; ++i) {
+            const int c256 = (2 * grp + i) * 64 + col;
+            f32x4 (&wcur)[8] = i ? wB : wA;
+            f32x4 (&wnxt)[8] = i ? wA : wB;
+            if (i == 0) load_w8(R5_w1 + (long)(c256 + 64) * 64 + 4 * half, wnxt);
+            else load_w8(R5_w2 + (long)col * 256 + 128 * grp + 4 * half, wnxt);     // first dense_2 chunk of this group
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             mma_w8(sa, wcur, acc);
-            const float bias = R6_b1[c256];
+            const float bias = gld(R5_b1 + (c256));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 const float uv = acc[r] + bias;
-                if (row < L) R6_u[(tok0 + row) * 256 + c256] = uv;
+                gst(row < L ? R5_u + ((tok0 + row) * 256 + c256) : trash, uv);
                 sU[row * FU + c256] = gelu_f(uv);
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     STAMP(6);
-    const auto R7_w2 = KARG(FusedFwdP, w2);
-    // ---- phase 6: dense_2 + dropout + residual + LayerNorm                        _modules.py:65-67
+    const auto R6_w2 = KARG(FusedFwdP, w2);
+    // ---- phase 6: dense_2 (K split: group g owns inner columns [128g, 128g+128)) + dropout + residual + LayerNorm
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* sa = sU + (wm * 32 + l31) * FU + 4 * half;
-        const float* gw = R7_w2 + (long)col * 256 + 4 * half;
+        const float* sa = sU + (wm * 32 + l31) * FU + 128 * grp + 4 * half;
+        load_w8(R6_w2 + (long)col * 256 + 128 * grp + 64 + 4 * half, wB);
+        mma_w8(sa, wA, acc);                                 // chunk 0 of this group sits in wA
+        mma_w8(sa + 64, wB, acc);
+        float* part = grp == 0 ? sX : sE;                    // sX / sE are dead: partial tiles
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {                     // chunk 0 sits in wA (loaded at the end of phase 5)
-            f32x4 (&wcur)[8] = (ch & 1) ? wB : wA;
-            f32x4 (&wnxt)[8] = (ch & 1) ? wA : wB;
-            if (ch < 3) load_w8(gw + 64 * (ch + 1), wnxt);
-            mma_w8(sa + 64 * ch, wcur, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sX[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];      // sX is dead: scratch tile
+        for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(7);
-    const auto R8_Xout = KARG(FusedFwdP, Xout);
-    const auto R8_b2 = KARG(FusedFwdP, b2);
-    const auto R8_drop_ff = KARG(FusedFwdP, drop_ff);
-    const auto R8_eps = KARG(FusedFwdP, eps);
-    const auto R8_ff_b = KARG(FusedFwdP, ff_b);
-    const auto R8_ff_g = KARG(FusedFwdP, ff_g);
-    const auto R8_rstd_ff = KARG(FusedFwdP, rstd_ff);
-    const auto R8_xhat_ff = KARG(FusedFwdP, xhat_ff);
-    ln_rows_64<false>(sX, R8_b2, sH, R8_drop_ff, R8_ff_g, R8_ff_b, R8_eps, nullptr, 0.f, 1.f, tok0, L, nullptr, R8_Xout,
-                      R8_xhat_ff, R8_rstd_ff);
+    const auto R7_Xout = KARG(FusedFwdP, Xout);
+    const auto R7_b2 = KARG(FusedFwdP, b2);
+    const auto R7_drop_ff = KARG(FusedFwdP, drop_ff);
+    const auto R7_eps = KARG(FusedFwdP, eps);
+    const auto R7_ff_b = KARG(FusedFwdP, ff_b);
+    const auto R7_ff_g = KARG(FusedFwdP, ff_g);
+    const auto R7_rstd_ff = KARG(FusedFwdP, rstd_ff);
+    const auto R7_xhat_ff = KARG(FusedFwdP, xhat_ff);
+    ln_rows_64<false>(sX, sE, R7_b2, sH, R7_drop_ff, R7_ff_g, R7_ff_b, R7_eps, nullptr, 0.f, 1.f, tok0, L, nullptr, R7_Xout,
+                      R7_xhat_ff, R7_rstd_ff);
     STAMP(8);
 }
 #undef PTYPE
 
 static inline size_t fused_fwd_smem_bytes() {
-    return (size_t)(3 * 64 * FS + 4 * 64 * FS + 2 * FUSED_MAX_CB * 128 + 64) * 4;
+    return (size_t)(8 * 64 * FS + 2 * FUSED_MAX_CB * 128 + 512 + 64) * 4;
 }
 
 // =============================================================================================
@@ -586,6 +655,7 @@ struct FusedBwdP {
     int L, Lp, cb, heads;
     float alpha, oma;
     DropP drop_f, drop_p, drop_o, drop_ff;
+    float* trash;
     long long* stamps;
 };
 
@@ -608,15 +678,15 @@ __device__ __forceinline__ void mma_rows_wT(const float* __restrict__ sa, const 
 __device__ __forceinline__ void seq_partial_64(const f32x4& v, float* __restrict__ red, float* __restrict__ dst, float scale_by = 1.f,
                                                const float* __restrict__ mul = nullptr) {
     const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
-    __syncthreads();
+    lds_barrier();
     st4(red + lr * 64 + lc, v);
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 64) {
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) s += red[g * 64 + threadIdx.x];
-        if (mul) s *= mul[threadIdx.x];
-        dst[threadIdx.x] = s * scale_by;
+        if (mul) s *= gld(mul + threadIdx.x);
+        gst(dst + threadIdx.x, s * scale_by);
     }
 }
 
@@ -649,6 +719,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;
     const int arow = (wm * 32 + l31) * FS + 4 * half;
+    float* const trash = KARG(FusedBwdP, trash) + 4 * lane;
 
     STAMP(0);
     const auto R1_cb = KARG(FusedBwdP, cb);
@@ -671,7 +742,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 
     // ---- stage A1: FeedForward LayerNorm backward (row pass): dz -> sAcc, dT2 -> sT, global
     {
-        const f32x4 g = ld4(R1_ff_g + lc);
+        const f32x4 g = gld4(R1_ff_g + lc);
         f32x4 sg = {0, 0, 0, 0}, sb = sg;
         f32x4 dy[4], xh[4];
         float rs[4];
@@ -683,9 +754,9 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             if (r < L) {
                 if (R1_dh_slabs) {                          // only the last position feeds the loss (bsarec.py:32)
                     if (r == L - 1)
-                        for (int sp = 0; sp < R1_dh_nsplit; ++sp) dy[i] += ld4(R1_dh_slabs + sp * R1_dh_stride + (long)b * 64 + lc);
-                } else dy[i] = ld4(R1_dY + e);
-                xh[i] = ld4(R1_xhat_ff + e); rs[i] = R1_rstd_ff[tok0 + r];
+                        for (int sp = 0; sp < R1_dh_nsplit; ++sp) dy[i] += gld4(R1_dh_slabs + sp * R1_dh_stride + (long)b * 64 + lc);
+                } else dy[i] = gld4(R1_dY + e);
+                xh[i] = gld4(R1_xhat_ff + e); rs[i] = gld(R1_rstd_ff + (tok0 + r));
             }
         }
 #pragma unroll
@@ -699,14 +770,14 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             const f32x4 dz = rs[i] * (gg - m1 - xh[i] * m2);
             sg += dy[i] * xh[i]; sb += dy[i];
             f32x4 dt = {0, 0, 0, 0};
-            if (ok) { dt = dz * drop_mult4(R1_drop_ff, (uint64_t)e >> 2); st4(R1_dT + e, dt); }
+            if (ok) { dt = dz * drop_mult4(R1_drop_ff, (uint64_t)e >> 2); gst4(R1_dT + e, dt); }
             st4(sAcc + r * FS + lc, dz);
             st4(sT + r * FS + lc, dt);
         }
         seq_partial_64(sg, sPm, R1_pg_ff + (long)b * 64);
         seq_partial_64(sb, sPm, R1_pb_ff + (long)b * 64);
     }
-    __syncthreads();
+    lds_barrier();
 
     STAMP(1);
     const auto R2_dU = KARG(FusedBwdP, dU);
@@ -727,7 +798,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
-                uv[r] = row < L ? R2_u[(tok0 + row) * 256 + c256] : 0.f;
+                uv[r] = gld(row < L ? R2_u + ((tok0 + row) * 256 + c256) : trash);
             }
             f32x16 acc;
 #pragma unroll
@@ -736,16 +807,14 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
-                float du = 0.f;
-                if (row < L) {
-                    du = acc[r] * gelu_grad_f(uv[r]);
-                    R2_dU[(tok0 + row) * 256 + c256] = du;
-                }
+                const bool ok = row < L;
+                const float du = ok ? acc[r] * gelu_grad_f(uv[r]) : 0.f;
+                gst(ok ? R2_dU + ((tok0 + row) * 256 + c256) : trash, du);
                 sdU[row * FU + c256] = du;
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     STAMP(2);
     const auto R3_w1 = KARG(FusedBwdP, w1);
@@ -768,7 +837,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sG[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
 
     STAMP(3);
     const auto R4_a_g = KARG(FusedBwdP, a_g);
@@ -792,7 +861,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     // ---- stage B1: alpha-mix + attention LayerNorm / filter LayerNorm backward (row pass)
     //      dO -> sT + global, dF -> sdF, dzA + dzF -> sAcc; q, k, v tiles -> LDS (dU is dead)
     {
-        const f32x4 ga = ld4(R4_a_g + lc), gf = ld4(R4_f_g + lc);
+        const f32x4 ga = gld4(R4_a_g + lc), gf = gld4(R4_f_g + lc);
         f32x4 sga = {0, 0, 0, 0}, sba = sga, sgf = sga, sbf = sga;
         f32x4 xa[4], xf[4];
         float ra[4], rf[4];
@@ -803,9 +872,9 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             f32x4 q4 = {0, 0, 0, 0}, k4 = q4, v4 = q4;
             xa[i] = q4; xf[i] = q4; ra[i] = 0.f; rf[i] = 0.f;
             if (r < L) {
-                xa[i] = ld4(R4_xhat_a + e); ra[i] = R4_rstd_a[tok0 + r];
-                xf[i] = ld4(R4_xhat_f + e); rf[i] = R4_rstd_f[tok0 + r];
-                q4 = ld4(R4_q + e); k4 = ld4(R4_k + e); v4 = ld4(R4_v + e);
+                xa[i] = gld4(R4_xhat_a + e); ra[i] = gld(R4_rstd_a + (tok0 + r));
+                xf[i] = gld4(R4_xhat_f + e); rf[i] = gld(R4_rstd_f + (tok0 + r));
+                q4 = gld4(R4_q + e); k4 = gld4(R4_k + e); v4 = gld4(R4_v + e);
             }
             st4(sQ + r * FS + lc, q4); st4(sK + r * FS + lc, k4); st4(sV + r * FS + lc, v4);
         }
@@ -828,7 +897,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             if (ok) {
                 dO = dza * drop_mult4(R4_drop_o, (uint64_t)e >> 2);
                 dF = dzf * drop_mult4(R4_drop_f, (uint64_t)e >> 2);
-                st4(R4_dO + e, dO);
+                gst4(R4_dO + e, dO);
             }
             st4(sAcc + r * FS + lc, dza + dzf);
             st4(sT + r * FS + lc, dO);
@@ -839,7 +908,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         seq_partial_64(sgf, sPm, R4_pg_f + (long)b * 64);
         seq_partial_64(sbf, sPm, R4_pb_f + (long)b * 64);
     }
-    __syncthreads();
+    lds_barrier();
 
     STAMP(4);
     // ---- stage B2: dC = dO . Wo -> sG            (Wo fragments were fetched into wA during stage A3)
@@ -851,7 +920,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sG[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
-    __syncthreads();
+    lds_barrier();
 
     STAMP(5);
     const auto R6_dk = KARG(FusedBwdP, dk);
@@ -880,7 +949,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                         pp[kt][g] = f32x4{0, 0, 0, 0}; mm[kt][g] = pp[kt][g];
                         if (query < L && key0 < Lp) {
                             const long e = (((long)b * heads + head) * L + query) * Lp + key0;
-                            pp[kt][g] = ld4(R6_probs + e);
+                            pp[kt][g] = gld4(R6_probs + e);
                             mm[kt][g] = drop_mult4(R6_drop_p, (uint64_t)e >> 2);
                         }
                     }
@@ -923,7 +992,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                             sS[(32 * kt + 8 * g + 4 * half + j) * FS + query] =
                                 pp[kt][g][j] * (da[kt][4 * g + j] - delta) * inv_sqrt_dh;
             }
-            __syncthreads();
+            lds_barrier();
             // C2: 6*NCT output tiles [32 tokens x 32 features]: dQ (rows = queries), dK, dV (rows = keys)
             f32x16 res[NRES];
 #pragma unroll
@@ -961,7 +1030,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                 }
                 res[ti] = acc;
             }
-            __syncthreads();                 // every read of this head's q / k / v columns is done
+            lds_barrier();                 // every read of this head's q / k / v columns is done
 #pragma unroll
             for (int ti = 0; ti < NRES; ++ti) {
                 const int t = wave + 4 * ti;
@@ -976,12 +1045,12 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                             const int row = 32 * rt + rho(r) + 4 * half;
                             const float val = rt < nt ? res[ti][r] : 0.f;
                             sdst[row * FS + hc + c] = val;
-                            if (row < L) gdst[(tok0 + row) * 64 + hc + c] = val;
+                            gst(row < L ? gdst + (tok0 + row) * 64 + hc + c : trash, val);
                         }
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
 
@@ -1007,7 +1076,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             sG[row * FS + col] = acc[r] + sAcc[row * FS + col];
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     STAMP(7);
     const auto R8_X = KARG(FusedBwdP, X);
@@ -1024,11 +1093,11 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         for (int r0 = 0; r0 < 64; r0 += 16) {
             const int r = r0 + lr;
             f32x4 x = {0, 0, 0, 0};
-            if (r < L) x = ld4(R8_X + (tok0 + r) * 64 + lc);
+            if (r < L) x = gld4(R8_X + (tok0 + r) * 64 + lc);
             st4(sXin + r * FS + lc, x);
         }
-        __syncthreads();
-        const f32x4 bt = ld4(R8_sqrt_beta + lc);
+        lds_barrier();
+        const f32x4 bt = gld4(R8_sqrt_beta + lc);
         const f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
         auto src = [&](int s, int t, int c) {
             return s == 0 ? ld4(sXin + t * FS + c) : ld4(sdF + t * FS + c) * omb2;
@@ -1042,7 +1111,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                 const f32x4 xv = ld4(sXin + t * FS + lc), df = ld4(sdF + t * FS + lc);
                 const f32x4 lowx = lowpass_tab(spec, t, lc, L, R8_cb, sTab);
                 const f32x4 lowg = lowpass_tab(spec + R8_cb * 128, t, lc, L, R8_cb, sTab);
-                st4(R8_dX + (tok0 + t) * 64 + lc, ld4(sG + t * FS + lc) + b2 * df + lowg);
+                gst4(R8_dX + (tok0 + t) * 64 + lc, ld4(sG + t * FS + lc) + b2 * df + lowg);
                 sb += df * (xv - lowx);
             }
         }
