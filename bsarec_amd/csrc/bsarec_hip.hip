@@ -434,7 +434,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
         if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
         ProfScope prof(BSAREC_K_FUSED_BWD, s); \
-        LAUNCH(fused_layer_bwd_kernel<DHV>, dim3(c.batch), dim3(256), smem, s, F); }
+        LAUNCH(fused_layer_bwd_kernel<DHV>, dim3(c.batch), dim3(512), smem, s, F); }
     if (p.dh == 16) FUSED_BWD_CASE(16) else if (p.dh == 32) FUSED_BWD_CASE(32) else FUSED_BWD_CASE(64)
 #undef FUSED_BWD_CASE
     return (int)hipGetLastError();

@@ -286,8 +286,15 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     const auto R1_ids32 = KARG(FusedFwdP, ids32);
     const auto R1_tw = KARG(FusedFwdP, tw);
     const auto R1_wq = KARG(FusedFwdP, wq);
+    // every global LOAD of a phase is issued before the phase's first global STORE: vmcnt retires in issue
+    // order, so a load queued behind stores would wait for their write acknowledgements
     f32x4 wA[8], wB[8];
-    if (grp == 1) load_w8(R1_wq + wrow, wA);
+    float qkv_bias[3] = {0.f, 0.f, 0.f};
+    if (grp == 1) {
+        load_w8(R1_wq + wrow, wA);
+        qkv_bias[0] = gld(KARG(FusedFwdP, bq) + col); qkv_bias[1] = gld(KARG(FusedFwdP, bk) + col);
+        qkv_bias[2] = gld(KARG(FusedFwdP, bv) + col);
+    }
     // ---- phase 0: sequence tile, ids, twiddle table -> LDS
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -327,12 +334,11 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float* bp = which == 0 ? R2_bq : which == 1 ? R2_bk : R2_bv;
             float* G = which == 0 ? R2_q : which == 1 ? R2_k : R2_v;
             if (which == 0) { load_w8(R2_wk + wrow, wB); mma_w8(sX + arow, wA, acc); }
             else if (which == 1) { load_w8(R2_wv + wrow, wA); mma_w8(sX + arow, wB, acc); }
             else mma_w8(sX + arow, wA, acc);
-            const float bias = gld(bp + col);
+            const float bias = qkv_bias[which];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
@@ -551,9 +557,11 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     const auto R4_rstd_a = KARG(FusedFwdP, rstd_a);
     const auto R4_w1 = KARG(FusedFwdP, w1);
     const auto R4_xhat_a = KARG(FusedFwdP, xhat_a);
+    float ffn_bias[2];
     // ---- phase 4: dense (K split across the groups) + dropout + residual + LayerNorm + alpha mix
     {
         load_w8(R4_w1 + (long)(128 * grp + col) * 64 + 4 * half, wA);      // first dense_1 block of this group
+        ffn_bias[0] = gld(KARG(FusedFwdP, b1) + 128 * grp + col); ffn_bias[1] = gld(KARG(FusedFwdP, b1) + 128 * grp + 64 + col);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -586,7 +594,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             mma_w8(sa, wcur, acc);
-            const float bias = gld(R5_b1 + (c256));
+            const float bias = ffn_bias[i];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
@@ -674,47 +682,62 @@ __device__ __forceinline__ void mma_rows_wT(const float* __restrict__ sa, const 
     }
 }
 
-// column sums held per lane (over this thread's rows) -> [64] partial of the sequence, via LDS scratch [16][64]
+// column sums held per lane (over this thread's rows) -> [64] partial of the sequence, via LDS scratch [rows][64]
 __device__ __forceinline__ void seq_partial_64(const f32x4& v, float* __restrict__ red, float* __restrict__ dst, float scale_by = 1.f,
                                                const float* __restrict__ mul = nullptr) {
     const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
+    const int ng = blockDim.x >> 4;
     lds_barrier();
     st4(red + lr * 64 + lc, v);
     lds_barrier();
     if (threadIdx.x < 64) {
         float s = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) s += red[g * 64 + threadIdx.x];
+        for (int g = 0; g < ng; ++g) s += red[g * 64 + threadIdx.x];
         if (mul) s *= gld(mul + threadIdx.x);
         gst(dst + threadIdx.x, s * scale_by);
     }
 }
 
+template <int LDW>
+__device__ __forceinline__ void load_wT4(const float* __restrict__ gw, f32x4 (&w)[4]) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        w[kb].x = gld(gw + (8 * kb + 0) * LDW); w[kb].y = gld(gw + (8 * kb + 1) * LDW);
+        w[kb].z = gld(gw + (8 * kb + 2) * LDW); w[kb].w = gld(gw + (8 * kb + 3) * LDW);
+    }
+}
+
+// Backward: 8 waves = 2 groups of 4, two waves per SIMD.  dU splits its four 64-wide blocks across the groups;
+// dH, dC and the QKV input-gradient split K (two partial tiles, summed by the next row pass); attention backward
+// runs (query tile, key tile) per wave and the 6 dQ/dK/dV tiles of a head on 6 of the 8 waves; the two DFT
+// sources of the FrequencyLayer backward run one per group.
 template <int DH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #define PTYPE FusedBwdP
     const auto R0_L = KARG(FusedBwdP, L);
     const auto R0_Lp = KARG(FusedBwdP, Lp);
+    const auto R0_cb = KARG(FusedBwdP, cb);
     const auto R0_heads = KARG(FusedBwdP, heads);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TS = 64 * FS;
-    float* sAcc = sm;                 // T0: dz (FFN) -> dzA + dzF
-    float* sT = sm + TS;              // T1: dT2 -> dO -> DFT spectrum
+    float* sAcc = sm;                 // T0: dz (FFN) -> dzA + dzF -> DFT spectra
+    float* sT = sm + TS;              // T1: dT2 -> dO -> x tile
     float* sQ = sm + 2 * TS;          // T2..T5 alias dU [64][FU] in the FFN stage and the DFT partials at the end
     float* sK = sm + 3 * TS;
     float* sV = sm + 4 * TS;
     float* sS = sm + 5 * TS;          // dS^T [key][query] of the current head
     float* sdU = sQ;
-    float* sG = sm + 6 * TS;          // T6: dH -> dC -> dX before the filter term
-    float* sdF = sm + 7 * TS;         // T7
-    float* sPm = sm + 8 * TS;         // T8: Drop(P)^T [key][query] of the current head | reduction scratch | x tile
+    float* sG = sm + 6 * TS;          // T6: partial tile 0 / dC / dX before the filter term
+    float* sdF = sm + 7 * TS;         // T7: partial tile of dH, then dF
+    float* sPm = sm + 8 * TS;         // T8: Drop(P)^T [key][query] | reduction scratch | partial tile 1
     float* sTab = sm + 9 * TS;        // FUSED_MAX_CB * 128
+    float* sRed = sTab + FUSED_MAX_CB * 128;   // 512: delta exchange [2 query tiles][2 key tiles][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int lr = tid >> 4, lc = (tid & 15) << 2;
-    const int L = R0_L, Lp = R0_Lp, heads = R0_heads;
+    const int L = R0_L, Lp = R0_Lp, heads = R0_heads, cb = R0_cb;
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;
@@ -722,11 +745,10 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     float* const trash = KARG(FusedBwdP, trash) + 4 * lane;
 
     STAMP(0);
-    const auto R1_cb = KARG(FusedBwdP, cb);
     const auto R1_dT = KARG(FusedBwdP, dT);
     const auto R1_dY = KARG(FusedBwdP, dY);
-    const auto R1_dh_slabs = KARG(FusedBwdP, dh_slabs);
     const auto R1_dh_nsplit = KARG(FusedBwdP, dh_nsplit);
+    const auto R1_dh_slabs = KARG(FusedBwdP, dh_slabs);
     const auto R1_dh_stride = KARG(FusedBwdP, dh_stride);
     const auto R1_drop_ff = KARG(FusedBwdP, drop_ff);
     const auto R1_ff_g = KARG(FusedBwdP, ff_g);
@@ -737,18 +759,18 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R1_w2 = KARG(FusedBwdP, w2);
     const auto R1_xhat_ff = KARG(FusedBwdP, xhat_ff);
     f32x4 wA[8], wB[8];
-    load_wT8<256>(R1_w2 + (long)(4 * half) * 256 + col, wA);          // first dU block
-    build_twiddle_table(R1_tw, L, R1_cb, sTab);
+    load_wT8<256>(R1_w2 + (long)(4 * half) * 256 + 128 * grp + col, wA);          // first dU block of this group
+    build_twiddle_table(R1_tw, L, cb, sTab);
 
     // ---- stage A1: FeedForward LayerNorm backward (row pass): dz -> sAcc, dT2 -> sT, global
     {
         const f32x4 g = gld4(R1_ff_g + lc);
         f32x4 sg = {0, 0, 0, 0}, sb = sg;
-        f32x4 dy[4], xh[4];
-        float rs[4];
+        f32x4 dy[2], xh[2];
+        float rs[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * i + lr;
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
             const long e = (tok0 + r) * 64 + lc;
             dy[i] = f32x4{0, 0, 0, 0}; xh[i] = dy[i]; rs[i] = 0.f;
             if (r < L) {
@@ -756,12 +778,12 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                     if (r == L - 1)
                         for (int sp = 0; sp < R1_dh_nsplit; ++sp) dy[i] += gld4(R1_dh_slabs + sp * R1_dh_stride + (long)b * 64 + lc);
                 } else dy[i] = gld4(R1_dY + e);
-                xh[i] = gld4(R1_xhat_ff + e); rs[i] = gld(R1_rstd_ff + (tok0 + r));
+                xh[i] = gld4(R1_xhat_ff + e); rs[i] = gld(R1_rstd_ff + tok0 + r);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * i + lr;
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
             const bool ok = r < L;
             const long e = (tok0 + r) * 64 + lc;
             const f32x4 gg = dy[i] * g;
@@ -784,22 +806,27 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R2_u = KARG(FusedBwdP, u);
     const auto R2_w1 = KARG(FusedBwdP, w1);
     const auto R2_w2 = KARG(FusedBwdP, w2);
-    // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU, global
+    // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU, global: group g owns blocks 2g, 2g+1
     {
         const float* sa = sT + arow;
-#pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            const int c256 = blk * 64 + col;
-            f32x4 (&wcur)[8] = (blk & 1) ? wB : wA;
-            f32x4 (&wnxt)[8] = (blk & 1) ? wA : wB;
-            if (blk < 3) load_wT8<256>(R2_w2 + (long)(4 * half) * 256 + c256 + 64, wnxt);
-            else load_wT8<64>(R2_w1 + (long)(4 * half) * 64 + col, wnxt);          // first dH chunk
-            float uv[16];
+        float uvA[16], uvB[16];
+        auto load_uv = [&](int blk, float (&uv)[16]) {      // pre-activations of block `blk` for this lane's 16 rows
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
-                uv[r] = gld(row < L ? R2_u + ((tok0 + row) * 256 + c256) : trash);
+                uv[r] = gld(row < L ? R2_u + ((tok0 + row) * 256 + blk * 64 + col) : trash);
             }
+        };
+        load_uv(2 * grp, uvA);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int blk = 2 * grp + i, c256 = blk * 64 + col;
+            f32x4 (&wcur)[8] = i ? wB : wA;
+            f32x4 (&wnxt)[8] = i ? wA : wB;
+            float (&uv)[16] = i ? uvB : uvA;
+            // loads of the NEXT product go out before this block's stores (vmcnt retires in issue order)
+            if (i == 0) { load_wT8<256>(R2_w2 + (long)(4 * half) * 256 + c256 + 64, wnxt); load_uv(blk + 1, uvB); }
+            else load_wT8<64>(R2_w1 + (long)(128 * grp + 4 * half) * 64 + col, wnxt);      // first dH chunk of this group
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -819,23 +846,20 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     STAMP(2);
     const auto R3_w1 = KARG(FusedBwdP, w1);
     const auto R3_wo = KARG(FusedBwdP, wo);
-    // ---- stage A3: dH = dU . W1 (+ dz in the row pass below) -> sG
+    // ---- stage A3: dH = dU . W1, K split: group g owns inner units [128g, 128g+128) -> partial tiles sG / sdF
+    f32x4 wO[4];
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* sa = sdU + (wm * 32 + l31) * FU + 4 * half;
-        const float* gw = R3_w1 + (long)(4 * half) * 64 + col;
+        const float* sa = sdU + (wm * 32 + l31) * FU + 128 * grp + 4 * half;
+        load_wT8<64>(R3_w1 + (long)(128 * grp + 64 + 4 * half) * 64 + col, wB);
+        load_wT4<64>(R3_wo + (long)(32 * grp + 4 * half) * 64 + col, wO);          // dense^T half for stage B2
+        mma_w8(sa, wA, acc);                                 // chunk 0 of this group sits in wA
+        mma_w8(sa + 64, wB, acc);
+        float* part = grp == 0 ? sG : sdF;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {                     // chunk 0 sits in wA
-            f32x4 (&wcur)[8] = (ch & 1) ? wB : wA;
-            f32x4 (&wnxt)[8] = (ch & 1) ? wA : wB;
-            if (ch < 3) load_wT8<64>(gw + (long)64 * (ch + 1) * 64, wnxt);
-            else load_wT8<64>(R3_wo + (long)(4 * half) * 64 + col, wnxt);         // dense weights for stage B2 (-> wA)
-            mma_w8(sa + 64 * ch, wcur, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sG[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
+        for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
     lds_barrier();
 
@@ -863,28 +887,28 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     {
         const f32x4 ga = gld4(R4_a_g + lc), gf = gld4(R4_f_g + lc);
         f32x4 sga = {0, 0, 0, 0}, sba = sga, sgf = sga, sbf = sga;
-        f32x4 xa[4], xf[4];
-        float ra[4], rf[4];
+        f32x4 xa[2], xf[2];
+        float ra[2], rf[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * i + lr;
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
             const long e = (tok0 + r) * 64 + lc;
             f32x4 q4 = {0, 0, 0, 0}, k4 = q4, v4 = q4;
             xa[i] = q4; xf[i] = q4; ra[i] = 0.f; rf[i] = 0.f;
             if (r < L) {
-                xa[i] = gld4(R4_xhat_a + e); ra[i] = gld(R4_rstd_a + (tok0 + r));
-                xf[i] = gld4(R4_xhat_f + e); rf[i] = gld(R4_rstd_f + (tok0 + r));
+                xa[i] = gld4(R4_xhat_a + e); ra[i] = gld(R4_rstd_a + tok0 + r);
+                xf[i] = gld4(R4_xhat_f + e); rf[i] = gld(R4_rstd_f + tok0 + r);
                 q4 = gld4(R4_q + e); k4 = gld4(R4_k + e); v4 = gld4(R4_v + e);
             }
             st4(sQ + r * FS + lc, q4); st4(sK + r * FS + lc, k4); st4(sV + r * FS + lc, v4);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 16 * i + lr;
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
             const bool ok = r < L;
             const long e = (tok0 + r) * 64 + lc;
             f32x4 dh = {0, 0, 0, 0};
-            if (ok) dh = ld4(sG + r * FS + lc) + ld4(sAcc + r * FS + lc);
+            if (ok) dh = ld4(sG + r * FS + lc) + ld4(sdF + r * FS + lc) + ld4(sAcc + r * FS + lc);
             const f32x4 dya = dh * R4_oma, dyf = dh * R4_alpha;
             const f32x4 g1 = dya * ga, g2 = dyf * gf;
             const float m1 = group_sum<16>(g1.x + g1.y + g1.z + g1.w) * (1.0f / 64.0f);
@@ -911,14 +935,21 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     lds_barrier();
 
     STAMP(4);
-    // ---- stage B2: dC = dO . Wo -> sG            (Wo fragments were fetched into wA during stage A3)
+    // ---- stage B2: dC = dO . Wo, K split across the groups (partials sG / sPm), then summed into sG
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w8(sT + arow, wA, acc);
+        mma_w4(sT + arow + 32 * grp, wO, acc);
+        float* part = grp == 0 ? sG : sPm;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sG[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
+        for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 32 * i + lr;
+        st4(sG + r * FS + lc, ld4(sG + r * FS + lc) + ld4(sPm + r * FS + lc));
     }
     lds_barrier();
 
@@ -933,71 +964,66 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         const int nt = (L + 31) >> 5;
         const float inv_sqrt_dh = 1.0f / sqrtf((float)DH);
         constexpr int NCT = (DH + 31) / 32;
-        constexpr int NRES = (6 * NCT + 3) / 4;
+        constexpr int NRES = (6 * NCT + 7) / 8;
         for (int head = 0; head < heads; ++head) {
             const int hc = head * DH;
-            // C1: waves 0..1 own one query tile each: Drop(P)^T -> sPm, dS^T -> sS   (as [key][query])
-            if (wave < 2) {
-                const int qt = wave;
-                const int query = 32 * qt + l31;
-                f32x4 pp[2][4], mm[2][4];
+            // C1: waves 0..3 own one (query tile, key tile) each: Drop(P)^T -> sPm, dS^T -> sS   (as [key][query])
+            const int qt = (wave >> 1) & 1, kt = wave & 1;
+            const int query = 32 * qt + l31;
+            const bool c1 = wave < 4;
+            f32x4 pp[4], mm[4];
+            f32x16 da;
+            float delta = 0.f;
+            if (c1) {
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int key0 = 32 * kt + 8 * g + 4 * half;
-                        pp[kt][g] = f32x4{0, 0, 0, 0}; mm[kt][g] = pp[kt][g];
-                        if (query < L && key0 < Lp) {
-                            const long e = (((long)b * heads + head) * L + query) * Lp + key0;
-                            pp[kt][g] = gld4(R6_probs + e);
-                            mm[kt][g] = drop_mult4(R6_drop_p, (uint64_t)e >> 2);
-                        }
-                    }
-                f32x16 da[2];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) da[kt][r] = 0.f;
-                    if (kt < nt && qt < nt) {
-                        const float* va = sV + (32 * kt + l31) * FS + hc + 4 * half;
-                        const float* cb_ = sG + query * FS + hc + 4 * half;
-#pragma unroll
-                        for (int kb = 0; kb < DH / 8; ++kb) {
-                            const f32x4 a = ld4(va + 8 * kb), c4 = ld4(cb_ + 8 * kb);
-#pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                da[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], c4[s], da[kt], 0, 0, 0);
-                        }
+                for (int g = 0; g < 4; ++g) {
+                    const int key0 = 32 * kt + 8 * g + 4 * half;
+                    pp[g] = f32x4{0, 0, 0, 0}; mm[g] = pp[g];
+                    if (query < L && key0 < Lp) {
+                        const long e = (((long)b * heads + head) * L + query) * Lp + key0;
+                        pp[g] = gld4(R6_probs + e);
+                        mm[g] = drop_mult4(R6_drop_p, (uint64_t)e >> 2);
                     }
                 }
-                float delta = 0.f;
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int r = 0; r < 16; ++r) da[r] = 0.f;
+                if (kt < nt && qt < nt) {
+                    const float* va = sV + (32 * kt + l31) * FS + hc + 4 * half;
+                    const float* cb_ = sG + query * FS + hc + 4 * half;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int kb = 0; kb < DH / 8; ++kb) {
+                        const f32x4 a = ld4(va + 8 * kb), c4 = ld4(cb_ + 8 * kb);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float dA = da[kt][4 * g + j] * mm[kt][g][j];
-                            delta += dA * pp[kt][g][j];
-                            da[kt][4 * g + j] = dA;
-                            sPm[(32 * kt + 8 * g + 4 * half + j) * FS + query] = pp[kt][g][j] * mm[kt][g][j];
-                        }
+                        for (int s = 0; s < 4; ++s) da = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], c4[s], da, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dA = da[4 * g + j] * mm[g][j];
+                        delta += dA * pp[g][j];
+                        da[4 * g + j] = dA;
+                        sPm[(32 * kt + 8 * g + 4 * half + j) * FS + query] = pp[g][j] * mm[g][j];
+                    }
                 delta = xor32_sum(delta);
+                sRed[(qt * 2 + kt) * 64 + lane] = delta;
+            }
+            lds_barrier();
+            if (c1) {
+                delta += sRed[(qt * 2 + (kt ^ 1)) * 64 + lane];      // the other key tile of this query tile
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            sS[(32 * kt + 8 * g + 4 * half + j) * FS + query] =
-                                pp[kt][g][j] * (da[kt][4 * g + j] - delta) * inv_sqrt_dh;
+                    for (int j = 0; j < 4; ++j)
+                        sS[(32 * kt + 8 * g + 4 * half + j) * FS + query] = pp[g][j] * (da[4 * g + j] - delta) * inv_sqrt_dh;
             }
             lds_barrier();
             // C2: 6*NCT output tiles [32 tokens x 32 features]: dQ (rows = queries), dK, dV (rows = keys)
             f32x16 res[NRES];
 #pragma unroll
             for (int ti = 0; ti < NRES; ++ti) {
-                const int t = wave + 4 * ti;
+                const int t = wave + 8 * ti;
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1030,10 +1056,10 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                 }
                 res[ti] = acc;
             }
-            lds_barrier();                 // every read of this head's q / k / v columns is done
+            lds_barrier();                   // every read of this head's q / k / v columns is done
 #pragma unroll
             for (int ti = 0; ti < NRES; ++ti) {
-                const int t = wave + 4 * ti;
+                const int t = wave + 8 * ti;
                 if (t < 6 * NCT) {
                     const int kind = t / (2 * NCT), rt = (t / NCT) & 1, ct = t % NCT;
                     const int c = 32 * ct + l31;
@@ -1058,67 +1084,102 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R7_wk = KARG(FusedBwdP, wk);
     const auto R7_wq = KARG(FusedBwdP, wq);
     const auto R7_wv = KARG(FusedBwdP, wv);
-    // ---- stage D: dQ.Wq + dK.Wk + dV.Wv + (dzA + dzF) -> sG
+    // ---- stage D: dQ.Wq + dK.Wk + dV.Wv, K = 192 split: group 0 = dQ.Wq + dK[:, :32].Wk[:32], group 1 = the rest
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const long wofs = (long)(4 * half) * 64 + col;
-        load_wT8<64>(R7_wq + wofs, wA);
-        load_wT8<64>(R7_wk + wofs, wB);
-        mma_w8(sQ + arow, wA, acc);
-        load_wT8<64>(R7_wv + wofs, wA);
-        mma_w8(sK + arow, wB, acc);
-        mma_w8(sV + arow, wA, acc);
+        f32x4 wk4[4];
+        if (grp == 0) { load_wT8<64>(R7_wq + wofs, wA); load_wT4<64>(R7_wk + wofs, wk4); }
+        else { load_wT4<64>(R7_wk + wofs + 32 * 64, wk4); load_wT8<64>(R7_wv + wofs, wA); }
+        mma_w8((grp == 0 ? sQ : sV) + arow, wA, acc);
+        mma_w4(sK + arow + 32 * grp, wk4, acc);
+        float* part = grp == 0 ? sG : sPm;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + rho(r) + 4 * half;
-            sG[row * FS + col] = acc[r] + sAcc[row * FS + col];
-        }
+        for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
     lds_barrier();
 
     STAMP(7);
     const auto R8_X = KARG(FusedBwdP, X);
-    const auto R8_cb = KARG(FusedBwdP, cb);
     const auto R8_dX = KARG(FusedBwdP, dX);
     const auto R8_pbeta = KARG(FusedBwdP, pbeta);
     const auto R8_sqrt_beta = KARG(FusedBwdP, sqrt_beta);
-    // ---- stage E: FrequencyLayer backward: dX = sG + beta^2 dF + lowpass((1-beta^2) dF); dbeta partial
+    // ---- stage E: FrequencyLayer backward: dX = (sG + sPm + sAcc) + beta^2 dF + lowpass((1-beta^2) dF); dbeta partial
     {
-        float* sXin = sPm;
-        float* spec = sT;                              // [2][cb][2][64]
-        float* part = sQ;                              // 16384 floats over T2..T5
+        float* sXin = sT;
+        float* spec = sAcc;                            // [2][cb][2][64]  (sAcc is folded into sG first)
+        float* part = (grp == 0 ? sQ : sV);            // [16][4][2][64] = 8192 floats per group (T2-T3 / T4-T5)
+        const f32x4 bt = gld4(R8_sqrt_beta + lc);
+        const f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
 #pragma unroll
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-            const int r = r0 + lr;
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
             f32x4 x = {0, 0, 0, 0};
             if (r < L) x = gld4(R8_X + (tok0 + r) * 64 + lc);
+            st4(sG + r * FS + lc, ld4(sG + r * FS + lc) + ld4(sPm + r * FS + lc) + ld4(sAcc + r * FS + lc));
             st4(sXin + r * FS + lc, x);
         }
         lds_barrier();
-        const f32x4 bt = gld4(R8_sqrt_beta + lc);
-        const f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
-        auto src = [&](int s, int t, int c) {
-            return s == 0 ? ld4(sXin + t * FS + c) : ld4(sdF + t * FS + c) * omb2;
-        };
-        dft_spectrum_tab<2>(src, L, R8_cb, sTab, spec, part);
+        // group 0 transforms x, group 1 transforms (1 - beta^2) dF: same code, same barriers
+        const int lr16 = (tid & 255) >> 4;
+        const float* srcT = grp == 0 ? sXin : sdF;
+        float* specg = spec + grp * cb * 128;
+#pragma unroll
+        for (int ch = 0; ch < FUSED_MAX_CB / 4; ++ch) {
+            const int k0 = 4 * ch;
+            if (k0 >= cb) break;
+            f32x4 re[4], im[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { re[j] = f32x4{0, 0, 0, 0}; im[j] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+            for (int r0 = 0; r0 < 64; r0 += 16) {
+                const int t = r0 + lr16;
+                if (t < L) {
+                    f32x4 x = ld4(srcT + t * FS + lc);
+                    if (grp == 1) x = x * omb2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j < cb) {
+                            const float c = sTab[2 * ((k0 + j) * 64 + t)], sn = sTab[2 * ((k0 + j) * 64 + t) + 1];
+                            re[j] += x * c; im[j] -= x * sn;
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                st4(part + ((lr16 * 4 + j) * 2 + 0) * 64 + lc, re[j]);
+                st4(part + ((lr16 * 4 + j) * 2 + 1) * 64 + lc, im[j]);
+            }
+            lds_barrier();
+            for (int i = tid & 255; i < 512; i += 256) {
+                const int j = i >> 7, rc = i & 127;
+                if (k0 + j < cb) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc += part[g * 512 + i];
+                    specg[(k0 + j) * 128 + rc] = acc;
+                }
+            }
+            lds_barrier();
+        }
         f32x4 sb = {0, 0, 0, 0};
 #pragma unroll
-        for (int r0 = 0; r0 < 64; r0 += 16) {
-            const int t = r0 + lr;
+        for (int i = 0; i < 2; ++i) {
+            const int t = 32 * i + lr;
             if (t < L) {
                 const f32x4 xv = ld4(sXin + t * FS + lc), df = ld4(sdF + t * FS + lc);
-                const f32x4 lowx = lowpass_tab(spec, t, lc, L, R8_cb, sTab);
-                const f32x4 lowg = lowpass_tab(spec + R8_cb * 128, t, lc, L, R8_cb, sTab);
+                const f32x4 lowx = lowpass_tab(spec, t, lc, L, cb, sTab);
+                const f32x4 lowg = lowpass_tab(spec + cb * 128, t, lc, L, cb, sTab);
                 gst4(R8_dX + (tok0 + t) * 64 + lc, ld4(sG + t * FS + lc) + b2 * df + lowg);
                 sb += df * (xv - lowx);
             }
         }
-        seq_partial_64(sb, part, R8_pbeta + (long)b * 64, 2.0f, R8_sqrt_beta);
+        seq_partial_64(sb, sQ, R8_pbeta + (long)b * 64, 2.0f, R8_sqrt_beta);
     }
     STAMP(8);
 }
 #undef PTYPE
 
-static inline size_t fused_bwd_smem_bytes() { return (size_t)(9 * 64 * FS + FUSED_MAX_CB * 128) * 4; }
+static inline size_t fused_bwd_smem_bytes() { return (size_t)(9 * 64 * FS + FUSED_MAX_CB * 128 + 512) * 4; }

@@ -4,7 +4,7 @@ Regions are delimited by STAMP(i); lines.  usage: kargify.py file kernel_name pa
 import re, sys
 
 def transform(s, kernel_name, ptype):
-    m = re.search(r"template <int DH>\n__global__ void __launch_bounds__\(\d+\)\n" + kernel_name, s)
+    m = re.search(r"template <int DH>\n__global__ void __launch_bounds__\(\d+\)[^\n]*\n" + kernel_name, s)
     a = m.start()
     e = s.index("    STAMP(8);\n}", a) + len("    STAMP(8);\n}")
     body = s[a:e]
