@@ -111,7 +111,9 @@ struct bsarec_plan {
     float *logits, *dlogits, *loss_rows, *loss;
     // backward scratch (shared by all layers)
     float *dXa, *dXb, *dz, *dT, *dU, *dH, *dXacc, *dO, *dF, *dC, *dS, *dq, *dk, *dv, *dXtmp, *dlast_slab;
-    float *slab_w, *slab_b, *part_ln, *part_beta, *trash;
+    float *slab_wL[BSAREC_MAX_LAYERS], *slab_bL[BSAREC_MAX_LAYERS], *part_lnL[BSAREC_MAX_LAYERS], *part_betaL[BSAREC_MAX_LAYERS];
+    float *slab_w, *slab_b, *part_ln, *part_beta;   // the current layer's set (selected by the backward loop)
+    float *part_ln0, *trash;
     ReduceJob* jobs; int jobs_per_layer;
 };
 
@@ -189,10 +191,14 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     p.dF = cv.take<float>(Td); p.dC = cv.take<float>(Td); p.dS = cv.take<float>(B * h * L * p.Lp);
     p.dq = cv.take<float>(Td); p.dk = cv.take<float>(Td); p.dv = cv.take<float>(Td); p.dXtmp = cv.take<float>(Td);
     p.dlast_slab = cv.take<float>((long)p.vsplit * B * d);
-    p.slab_w = cv.take<float>((long)p.nsplit * 12 * d * d);      // wq wk wv wo (d*d each) + w1 w2 (4 d*d each)
-    p.slab_b = cv.take<float>((long)p.nsplit * 9 * d);           // bq bk bv bo (d) + b1 (4d) + b2 (d)
-    p.part_ln = cv.take<float>((long)p.nblk * 6 * d);            // gamma/beta partials of the 3 LayerNorms
-    p.part_beta = cv.take<float>(B * d);
+    for (int l = 0; l < N; ++l) {                                // per layer, so that ONE reduction launch ends the backward
+        p.slab_wL[l] = cv.take<float>((long)p.nsplit * 12 * d * d);  // wq wk wv wo (d*d each) + w1 w2 (4 d*d each)
+        p.slab_bL[l] = cv.take<float>((long)p.nsplit * 9 * d);       // bq bk bv bo (d) + b1 (4d) + b2 (d)
+        p.part_lnL[l] = cv.take<float>((long)p.nblk * 6 * d);        // gamma/beta partials of the 3 LayerNorms
+        p.part_betaL[l] = cv.take<float>(B * d);
+    }
+    p.slab_w = p.slab_wL[0]; p.slab_b = p.slab_bL[0]; p.part_ln = p.part_lnL[0]; p.part_beta = p.part_betaL[0];
+    p.part_ln0 = cv.take<float>((long)p.nblk * 2 * d);
     p.trash = cv.take<float>(1024);
     *total = cv.off;
 }
@@ -250,6 +256,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     const int ns = p->nsplit, nb = p->nblk;
     for (int l = 0; l < cfg->layers; ++l) {
         const bsarec_layer_t& g = p->G.layer[l];
+        p->slab_w = p->slab_wL[l]; p->slab_b = p->slab_bL[l]; p->part_ln = p->part_lnL[l]; p->part_beta = p->part_betaL[l];
         add(p->part_beta, g.sqrt_beta, cfg->batch, d);
         add(p->part_ln + 4L * nb * d, g.filter_ln_w, nb, d);
         add(p->part_ln + 5L * nb * d, g.filter_ln_b, nb, d);
@@ -264,8 +271,8 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
         add(p->part_ln + 0L * nb * d, g.ffn_ln_w, nb, d);
         add(p->part_ln + 1L * nb * d, g.ffn_ln_b, nb, d);
     }
-    add(p->part_ln + 0L * nb * d, p->G.ln_w, nb, d);
-    add(p->part_ln + 1L * nb * d, p->G.ln_b, nb, d);
+    add(p->part_ln0 + 0L * nb * d, p->G.ln_w, nb, d);
+    add(p->part_ln0 + 1L * nb * d, p->G.ln_b, nb, d);
     p->jobs_per_layer = 19;
     hipError_t e = hipMemcpyAsync(p->jobs, jobs.data(), jobs.size() * sizeof(ReduceJob), hipMemcpyHostToDevice,
                                   (hipStream_t)stream);
@@ -589,21 +596,30 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
     const int ns = p->nsplit, nb = p->nblk;
     const float* hlast = p->X[N] + (long)(L - 1) * d;
 
-    // dE (dense, logits path) = dlogits^T . h_last       [V, d], overwrites the gradient buffer
+    // dE (dense, logits path) = dlogits^T . h_last  [V, d] (overwrites the gradient buffer) and the split-K slabs of
+    // d(h_last) = dlogits . E -- one launch
     {
-        GemmP g = gemm_defaults(c.item_size, d, B);
-        g.lda = p->Vp; g.ldb = (long)L * d; g.A[0] = p->dlogits; g.B[0] = hlast;
-        auto e = epi_linear<false, false, false>(p->G.item_emb, d);
-        RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
-    }
-    // d(h_last) = dlogits . E, split-K over the catalogue, then scatter into the (otherwise zero) dX^N
-    {
-        GemmP g = gemm_defaults(B, d, p->Vp);
-        g.Kv = c.item_size; g.lda = p->Vp; g.ldb = d; g.A[0] = p->dlogits; g.B[0] = p->P.item_emb;
-        g.nsplit = p->vsplit; g.kchunk = p->vchunk;
-        auto e = epi_linear<false, false, false>(p->dlast_slab, d);
-        e.c_split = (long)B * d;
-        RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
+        PairP G;
+        memset(&G, 0, sizeof(G));
+        G.A = gemm_defaults(c.item_size, d, B);
+        G.A.lda = p->Vp; G.A.ldb = (long)L * d; G.A.A[0] = p->dlogits; G.A.B[0] = hlast;
+        G.EA = epi_linear<false, false, false>(p->G.item_emb, d);
+        G.B = gemm_defaults(B, d, p->Vp);
+        G.B.Kv = c.item_size; G.B.lda = p->Vp; G.B.ldb = d; G.B.A[0] = p->dlogits; G.B.B[0] = p->P.item_emb;
+        G.B.nsplit = p->vsplit; G.B.kchunk = p->vchunk;
+        G.EB = epi_linear<false, false, false>(p->dlast_slab, d);
+        G.EB.c_split = (long)B * d;
+        G.tilesA = cdiv(c.item_size, 64) * cdiv(d, 64);
+        G.tilesB_m = cdiv(B, 64);
+        if (d <= 64) {
+            constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES > GemmSmem<64, 64, false, true>::BYTES
+                                        ? GemmSmem<64, 64, true, true>::BYTES : GemmSmem<64, 64, false, true>::BYTES;
+            LAUNCH(gemm_logits_bwd_kernel, dim3(G.tilesA + G.tilesB_m * p->vsplit), dim3(GEMM_THREADS), smem, s, G);
+            HIPCHK(hipGetLastError());
+        } else {                                   // wider hidden sizes: two plain launches (N needs several tiles)
+            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, false>(G.A, nox, G.EA, nullptr, 1, s)));
+            RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(G.B, nox, G.EB, nullptr, 1, s)));
+        }
     }
     float* dY = (N & 1) ? p->dXb : p->dXa;       // gradient w.r.t. X[l+1]; ping-pong so that dX[0] lands in dXa
     if (!p->fused) {      // the fused top-layer backward synthesises this gradient from the slabs itself
@@ -617,6 +633,7 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         LayerBufs& b = p->lb[l];
         const float* X = p->X[l];
         float* dXout = (dY == p->dXa) ? p->dXb : p->dXa;
+        p->slab_w = p->slab_wL[l]; p->slab_b = p->slab_bL[l]; p->part_ln = p->part_lnL[l]; p->part_beta = p->part_betaL[l];
         if (p->fused) {
             RET(launch_fused_bwd(*p, l, tr, dY, dXout, s, l == N - 1));
         } else {
@@ -736,8 +753,6 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         if (!p->fused)
             DISPATCH_LPR(d, RET(launch_freq_bwd<LPR>(X, p->dF, p->dXtmp, w.sqrt_beta, p->twiddle, B, L, d, c.cutoff_bins,
                                                      dXout, p->part_beta, s)));
-        // ---- second-stage reductions of this layer's 19 tensors
-        RET(launch_reduce(p->jobs + (long)l * p->jobs_per_layer, p->jobs_per_layer, 4L * d * d, s));
         dY = dXout;
     }
     // ---- embedding front-end backward
@@ -745,7 +760,7 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
         LnBranch a; memset(&a, 0, sizeof(a));
         a.xhat = p->xhat0; a.rstd = p->rstd0; a.gamma = p->P.ln_w; a.in_scale = 1.f;
         a.drop = make_drop(*p, c.p_hidden, 0, tr); a.dT = nullptr;
-        a.pgamma = p->part_ln + 0L * nb * d; a.pbeta = p->part_ln + 1L * nb * d;
+        a.pgamma = p->part_ln0 + 0L * nb * d; a.pbeta = p->part_ln0 + 1L * nb * d;
         DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, p->rows_pb));
         HIPCHK(hipGetLastError());
         DISPATCH_LPR(d, {
@@ -762,7 +777,8 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
                    p->G.item_emb, p->G.pos_emb, sb);
             HIPCHK(hipGetLastError());
         });
-        RET(launch_reduce(p->jobs + (long)N * p->jobs_per_layer, 2, d, s));
+        // ---- ONE deterministic second-stage reduction for every split-K slab and LayerNorm / beta partial
+        RET(launch_reduce(p->jobs, N * p->jobs_per_layer + 2, 4L * d * d, s));
     }
     return 0;
 }

@@ -181,3 +181,27 @@ gemm_grouped_tn_kernel(const GroupedTN G) {
     else
         gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The two products of the logits backward in ONE launch: dE = dlogits^T . h_last (TN, [V, d]) and the split-K
+// slabs of d(h_last) = dlogits . E (NN).  blockIdx.x < tilesA -> problem A, else problem B.
+// ---------------------------------------------------------------------------------------------
+struct PairP {
+    GemmP A, B;
+    EpiLinear<false, false, false> EA, EB;
+    int tilesA, tilesB_m;          // B: blocks = tilesB_m (m tiles) x B.nsplit
+};
+
+__global__ void __launch_bounds__(GEMM_THREADS)
+gemm_logits_bwd_kernel(const PairP G) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    XformP X;
+    X.L = 0; X.Lp = 0; X.drop.thresh = 0; X.drop.scale = 1.f; X.drop.rng = nullptr; X.drop.site = 0;
+    const int bx = blockIdx.x;
+    if (bx < G.tilesA)
+        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, false>(G.A, X, G.EA, nullptr, bx, 0, 0, smem);
+    else {
+        const int r = bx - G.tilesA;
+        gemm_body<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(G.B, X, G.EB, nullptr, r % G.tilesB_m, 0, r / G.tilesB_m, smem);
+    }
+}

@@ -429,15 +429,14 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int j = lr + p * RPP;
-            if (colok && j < n && sid[j] != 0 && lead[j] == j) {
-                const f32x4 r = ld4(acc + j * W + lc);
-                float* dst = dE + (long)sid[j] * d + lc;
-                unsafeAtomicAdd(dst + 0, r.x); unsafeAtomicAdd(dst + 1, r.y);
-                unsafeAtomicAdd(dst + 2, r.z); unsafeAtomicAdd(dst + 3, r.w);
-            }
+        // one leader row per wave-instruction: lane = column, so every global_atomic_add_f32 covers 256 contiguous
+        // bytes (the full-rate shape; 4-byte pieces at a 16-byte stride run ~17x slower)
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int j = wv; j < n; j += ROW_THREADS / 64) {
+            const int id = sid[j];
+            if (id == 0 || lead[j] != j) continue;        // wave-uniform
+            for (int c0 = 0; c0 < d; c0 += 64)
+                if (c0 + lane < d) unsafeAtomicAdd(dE + (long)id * d + c0 + lane, acc[j * W + c0 + lane]);
         }
         return;
     }
