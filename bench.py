@@ -126,7 +126,7 @@ def main():
         perm_state["pos"] = 0
 
     def step_body():
-        if world == 1:
+        if pg is None:
             return model.train_step_indexed(batches.inputs, batches.answers, perm_buf, cursor, B)
         plan = model._plan(B)
         if not hasattr(plan, "ids_buf"):

@@ -178,6 +178,16 @@ __device__ __forceinline__ void mma_w8(const float* __restrict__ sa, const f32x4
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
     }
 }
+// same, with erf-GELU applied to the A operand as it is read (dense_2 consumes gelu(u); u itself is what is stored)
+__device__ __forceinline__ void mma_w8_gelu(const float* __restrict__ sa, const f32x4 (&w)[8], f32x16& acc) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        f32x4 a = ld4(sa + 8 * kb);
+        a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
+    }
+}
 template <int LDW>
 __device__ __forceinline__ void load_wT8(const float* __restrict__ gw, f32x4 (&w)[8]) {
 #pragma unroll
@@ -334,7 +344,6 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            float* G = which == 0 ? R2_q : which == 1 ? R2_k : R2_v;
             if (which == 0) { load_w8(R2_wk + wrow, wB); mma_w8(sX + arow, wA, acc); }
             else if (which == 1) { load_w8(R2_wv + wrow, wA); mma_w8(sX + arow, wB, acc); }
             else mma_w8(sX + arow, wA, acc);
@@ -346,7 +355,6 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
                 if (which == 0) sQ[row * FS + col] = val;
                 else if (which == 1) sK[row * FS + col] = val;
                 else sVt[col * FS + row] = val;
-                gst(row < L ? G + (tok0 + row) * 64 + col : trash, val);
             }
         };
 #pragma unroll
@@ -428,6 +436,20 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     f32x4 wO[4];
     load_w4(R2_wo + wrow + 32 * grp, wO);
     lds_barrier();
+    // q, k, v -> global as whole rows, 16 B per lane (per-lane dword stores are store-issue bound)
+    {
+        const int lr = tid >> 4, lc = (tid & 15) << 2;
+#pragma unroll
+        for (int r0 = 0; r0 < 64; r0 += 32) {
+            const int r = r0 + lr;
+            if (r < L) {
+                const long e = (tok0 + r) * 64 + lc;
+                gst4(R2_q + e, ld4(sQ + r * FS + lc));
+                gst4(R2_k + e, ld4(sK + r * FS + lc));
+                gst4(R2_v + e, f32x4{sVt[lc * FS + r], sVt[(lc + 1) * FS + r], sVt[(lc + 2) * FS + r], sVt[(lc + 3) * FS + r]});
+            }
+        }
+    }
 
     STAMP(3);
     const auto R3_ctx = KARG(FusedFwdP, ctx);
@@ -580,7 +602,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     const auto R5_u = KARG(FusedFwdP, u);
     const auto R5_w1 = KARG(FusedFwdP, w1);
     const auto R5_w2 = KARG(FusedFwdP, w2);
-    // ---- phase 5: dense_1 + erf-GELU -> sU (and pre-activation u -> global): group g owns blocks 2g, 2g+1
+    // ---- phase 5: dense_1 pre-activation -> sU: group g owns blocks 2g, 2g+1
     {
         const float* sa = sH + arow;
 #pragma unroll
@@ -598,9 +620,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
-                const float uv = acc[r] + bias;
-                gst(row < L ? R5_u + ((tok0 + row) * 256 + c256) : trash, uv);
-                sU[row * FU + c256] = gelu_f(uv);
+                sU[row * FU + c256] = acc[r] + bias;
             }
         }
     }
@@ -608,8 +628,19 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 
     STAMP(6);
     const auto R6_w2 = KARG(FusedFwdP, w2);
-    // ---- phase 6: dense_2 (K split: group g owns inner columns [128g, 128g+128)) + dropout + residual + LayerNorm
+    const auto R6_u = KARG(FusedFwdP, u);
+    // ---- phase 6: u write-out + erf-GELU pass, dense_2 (K split: group g owns inner columns [128g, 128g+128)) + dropout + residual + LN
     {
+        // pre-activation u -> global as whole rows (the backward needs it for gelu'); gelu(u) replaces it in LDS,
+        // once per element (applying it in dense_2's operand loads would evaluate it once per column tile)
+        for (int idx = tid; idx < 64 * 64; idx += 512) {
+            const int r = idx >> 6, c4 = (idx & 63) << 2;
+            f32x4 v = ld4(sU + r * FU + c4);
+            if (r < L) gst4(R6_u + (tok0 + r) * 256 + c4, v);
+            v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+            st4(sU + r * FU + c4, v);
+        }
+        lds_barrier();
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -761,6 +792,15 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     f32x4 wA[8], wB[8];
     load_wT8<256>(R1_w2 + (long)(4 * half) * 256 + 128 * grp + col, wA);          // first dU block of this group
     build_twiddle_table(R1_tw, L, cb, sTab);
+    {   // pre-activation tile u [64][256] -> LDS (whole rows, 16 B per lane); consumed by stage A2
+        const float* gu = KARG(FusedBwdP, u);
+        for (int idx = tid; idx < 64 * 64; idx += 512) {
+            const int r = idx >> 6, c4 = (idx & 63) << 2;
+            f32x4 v = {0, 0, 0, 0};
+            if (r < L) v = gld4(gu + (tok0 + r) * 256 + c4);
+            st4(sdU + r * FU + c4, v);
+        }
+    }
 
     // ---- stage A1: FeedForward LayerNorm backward (row pass): dz -> sAcc, dT2 -> sT, global
     {
@@ -806,26 +846,15 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R2_u = KARG(FusedBwdP, u);
     const auto R2_w1 = KARG(FusedBwdP, w1);
     const auto R2_w2 = KARG(FusedBwdP, w2);
-    // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU, global: group g owns blocks 2g, 2g+1
+    // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU (in place over the staged u tile): group g owns blocks 2g, 2g+1
     {
         const float* sa = sT + arow;
-        float uvA[16], uvB[16];
-        auto load_uv = [&](int blk, float (&uv)[16]) {      // pre-activations of block `blk` for this lane's 16 rows
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + rho(r) + 4 * half;
-                uv[r] = gld(row < L ? R2_u + ((tok0 + row) * 256 + blk * 64 + col) : trash);
-            }
-        };
-        load_uv(2 * grp, uvA);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int blk = 2 * grp + i, c256 = blk * 64 + col;
             f32x4 (&wcur)[8] = i ? wB : wA;
             f32x4 (&wnxt)[8] = i ? wA : wB;
-            float (&uv)[16] = i ? uvB : uvA;
-            // loads of the NEXT product go out before this block's stores (vmcnt retires in issue order)
-            if (i == 0) { load_wT8<256>(R2_w2 + (long)(4 * half) * 256 + c256 + 64, wnxt); load_uv(blk + 1, uvB); }
+            if (i == 0) load_wT8<256>(R2_w2 + (long)(4 * half) * 256 + c256 + 64, wnxt);
             else load_wT8<64>(R2_w1 + (long)(128 * grp + 4 * half) * 64 + col, wnxt);      // first dH chunk of this group
             f32x16 acc;
 #pragma unroll
@@ -834,14 +863,17 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
-                const bool ok = row < L;
-                const float du = ok ? acc[r] * gelu_grad_f(uv[r]) : 0.f;
-                gst(ok ? R2_dU + ((tok0 + row) * 256 + c256) : trash, du);
-                sdU[row * FU + c256] = du;
+                float* pu = sdU + row * FU + c256;
+                *pu = row < L ? acc[r] * gelu_grad_f(*pu) : 0.f;
             }
         }
     }
     lds_barrier();
+    // dU -> global as whole rows, 16 B per lane (operand of the dense_1 weight gradient)
+    for (int idx = tid; idx < 64 * 64; idx += 512) {
+        const int r = idx >> 6, c4 = (idx & 63) << 2;
+        if (r < L) gst4(R2_dU + (tok0 + r) * 256 + c4, ld4(sdU + r * FU + c4));
+    }
 
     STAMP(2);
     const auto R3_w1 = KARG(FusedBwdP, w1);
@@ -1065,18 +1097,27 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                     const int c = 32 * ct + l31;
                     if (c < DH) {
                         float* sdst = kind == 0 ? sQ : kind == 1 ? sK : sV;      // in place: dq, dk, dv
-                        float* gdst = kind == 0 ? R6_dq : kind == 1 ? R6_dk : R6_dv;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = 32 * rt + rho(r) + 4 * half;
                             const float val = rt < nt ? res[ti][r] : 0.f;
                             sdst[row * FS + hc + c] = val;
-                            gst(row < L ? gdst + (tok0 + row) * 64 + hc + c : trash, val);
                         }
                     }
                 }
             }
             lds_barrier();
+        }
+        // dq, dk, dv -> global as whole rows, 16 B per lane (operands of the Q/K/V weight gradients)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
+            if (r < L) {
+                const long e = (tok0 + r) * 64 + lc;
+                gst4(R6_dq + e, ld4(sQ + r * FS + lc));
+                gst4(R6_dk + e, ld4(sK + r * FS + lc));
+                gst4(R6_dv + e, ld4(sV + r * FS + lc));
+            }
         }
     }
 

@@ -51,7 +51,8 @@ class Trainer:
         self.logger.info(f"Total Parameters: {sum(p.nelement() for p in self.model.parameters())}")
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
-        self.use_graph = use_graph and self.world == 1
+        self.dp = process_group is not None            # data-parallel step (all-reduce), even for a 1-rank group
+        self.use_graph = use_graph and not self.dp
         self._graphs = {}
         self._seen_cache = {}
 
@@ -97,7 +98,7 @@ class Trainer:
     # ---- one optimisation step --------------------------------------------------------------------
     def _step_eager(self, ids, ans):
         m = self.model
-        if self.world == 1:
+        if not self.dp:
             return m.train_step(ids, ans)
         # data parallel: local forward/backward, ONE summing all-reduce of the flat gradient arena
         # (RCCL over xGMI), Adam on the mean; every rank holds identical replicas
@@ -149,7 +150,7 @@ class Trainer:
         self._loss_sum.zero_()
 
         def body():
-            if self.world == 1:
+            if not self.dp:
                 loss = m.train_step_indexed(dl.inputs, dl.answers, pbuf, self._cursor, B)
             else:
                 plan = m._plan(B)
