@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define RET(x) do { int r_ = (x); if (r_ != 0) return r_; } while (0)
@@ -113,7 +114,8 @@ struct bsarec_plan {
     float *dXa, *dXb, *dz, *dT, *dU, *dH, *dXacc, *dO, *dF, *dC, *dS, *dq, *dk, *dv, *dXtmp, *dlast_slab;
     float *slab_wL[BSAREC_MAX_LAYERS], *slab_bL[BSAREC_MAX_LAYERS], *part_lnL[BSAREC_MAX_LAYERS], *part_betaL[BSAREC_MAX_LAYERS];
     float *slab_w, *slab_b, *part_ln, *part_beta;   // the current layer's set (selected by the backward loop)
-    float *part_ln0, *trash;
+    float *part_ln0, *part_pos, *trash;
+    int pos_slices;
     ReduceJob* jobs; int jobs_per_layer;
 };
 
@@ -172,7 +174,7 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     const long T = p.T, d = c.hidden, B = c.batch, L = c.seq_len, h = c.heads, N = c.layers;
     const long Td = T * d;
     Carver cv(base);
-    p.jobs = cv.take<ReduceJob>((size_t)(N * 19 + 2));
+    p.jobs = cv.take<ReduceJob>((size_t)(N * 19 + 3));
     p.ids32 = cv.take<int>(T);
     for (int l = 0; l <= N; ++l) p.X[l] = cv.take<float>(Td);
     p.xhat0 = cv.take<float>(Td); p.rstd0 = cv.take<float>(T);
@@ -199,6 +201,8 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     }
     p.slab_w = p.slab_wL[0]; p.slab_b = p.slab_bL[0]; p.part_ln = p.part_lnL[0]; p.part_beta = p.part_betaL[0];
     p.part_ln0 = cv.take<float>((long)p.nblk * 2 * d);
+    p.pos_slices = cdiv(B, 64);
+    p.part_pos = cv.take<float>((long)p.pos_slices * L * d);
     p.trash = cv.take<float>(1024);
     *total = cv.off;
 }
@@ -273,6 +277,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     }
     add(p->part_ln0 + 0L * nb * d, p->G.ln_w, nb, d);
     add(p->part_ln0 + 1L * nb * d, p->G.ln_b, nb, d);
+    add(p->part_pos, p->G.pos_emb, p->pos_slices, (long)cfg->seq_len * d);
     p->jobs_per_layer = 19;
     hipError_t e = hipMemcpyAsync(p->jobs, jobs.data(), jobs.size() * sizeof(ReduceJob), hipMemcpyHostToDevice,
                                   (hipStream_t)stream);
@@ -773,12 +778,12 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
                 attr = true;
             }
             const int sb = cdiv(T, CHUNK);
-            LAUNCH(embed_bwd_kernel<LPR>, dim3(sb + L), dim3(ROW_THREADS), smem, s, p->dz, p->ids32, B, L, d,
-                   p->G.item_emb, p->G.pos_emb, sb);
+            LAUNCH(embed_bwd_kernel<LPR>, dim3(sb + L * p->pos_slices), dim3(ROW_THREADS), smem, s, p->dz, p->ids32, B, L, d,
+                   p->G.item_emb, p->part_pos, sb);
             HIPCHK(hipGetLastError());
         });
         // ---- ONE deterministic second-stage reduction for every split-K slab and LayerNorm / beta partial
-        RET(launch_reduce(p->jobs, N * p->jobs_per_layer + 2, 4L * d * d, s));
+        RET(launch_reduce(p->jobs, N * p->jobs_per_layer + 3, std::max(4L * d * d, (long)L * d), s));
     }
     return 0;
 }

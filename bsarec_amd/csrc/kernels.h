@@ -405,10 +405,16 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
         for (int i = threadIdx.x; i < CHUNK; i += ROW_THREADS) sid[i] = i < n ? ids32[t0 + i] : 0;
         for (int i = threadIdx.x; i < SCATTER_FLOATS / 4; i += ROW_THREADS) st4(acc + 4 * i, f32x4{0, 0, 0, 0});
         __syncthreads();
-        for (int j = threadIdx.x; j < CHUNK; j += ROW_THREADS) {
-            const int id = sid[j];
+        for (int j = threadIdx.x; j < CHUNK; j += ROW_THREADS) {      // first occurrence of sid[j]: 4 ids per LDS read,
+            const int id = sid[j];                                    // no early exit (independent, pipelined reads)
             int l = j;
-            for (int i = 0; i < j; ++i) if (sid[i] == id) { l = i; break; }
+            for (int i = CHUNK - 4; i >= 0; i -= 4) {
+                const int4 q = *reinterpret_cast<const int4*>(sid + i);
+                if (q.w == id && i + 3 < l) l = i + 3;
+                if (q.z == id && i + 2 < l) l = i + 2;
+                if (q.y == id && i + 1 < l) l = i + 1;
+                if (q.x == id && i < l) l = i;
+            }
             lead[j] = l;
         }
         __syncthreads();
@@ -441,17 +447,21 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
         return;
     }
     float (*red)[W] = reinterpret_cast<float (*)[W]>(esm);
-    const int t = blockIdx.x - scatter_blocks;       // one block per position
+    // position gradient: block (t, slice) sums de[b, t, :] over the 64 sequences of its slice -> dPos partial
+    // [slice][L][d]; the slices are summed by multi_reduce_kernel (deterministic)
+    const int pb = blockIdx.x - scatter_blocks;
+    const int t = pb % L, slice = pb / L;
+    const int b0 = slice * 64, b1 = min(B, b0 + 64);
     f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
     if (colok) {
-        int bb = lr;
-        for (; bb + 3 * RPP < B; bb += 4 * RPP) {
+        int bb = b0 + lr;
+        for (; bb + 3 * RPP < b1; bb += 4 * RPP) {
             s0 += ld4(de + ((long)bb * L + t) * d + lc);
             s1 += ld4(de + ((long)(bb + RPP) * L + t) * d + lc);
             s2 += ld4(de + ((long)(bb + 2 * RPP) * L + t) * d + lc);
             s3 += ld4(de + ((long)(bb + 3 * RPP) * L + t) * d + lc);
         }
-        for (; bb < B; bb += RPP) s0 += ld4(de + ((long)bb * L + t) * d + lc);
+        for (; bb < b1; bb += RPP) s0 += ld4(de + ((long)bb * L + t) * d + lc);
     }
     st4(&red[lr][lc], (s0 + s1) + (s2 + s3));
     __syncthreads();
@@ -459,7 +469,7 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
         float a = 0.f;
 #pragma unroll
         for (int g = 0; g < RPP; ++g) a += red[g][c];
-        dPos[(long)t * d + c] = a;
+        dPos[((long)slice * L + t) * d + c] = a;
     }
 }
 
