@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include <algorithm>
@@ -157,7 +158,9 @@ static void derive(bsarec_plan& p) {
     p.nblk = p.fused ? c.batch : cdiv(p.T, 64);
     p.rows_pb = p.fused ? c.seq_len : 64;
     // split-K over tokens for the weight-gradient products: ~40 slices, 32-aligned chunks
-    long ch = rup(cdiv(p.T, 40), GEMM_BK);
+    int want_splits = 40;
+    if (const char* e = getenv("BSAREC_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) want_splits = v; }   // tuning knob
+    long ch = rup(cdiv(p.T, want_splits), GEMM_BK);
     if (ch < 64) ch = 64;
     if (ch > 2048) ch = 2048;
     p.kchunk = (int)ch;
@@ -398,7 +401,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     F.tw = p.twiddle; F.ids32 = p.ids32;
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs; F.ctx = b.ctx;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.hmix = b.hmix; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
-    F.dsp = b.dsp;
+    F.dsp = nullptr;          // FrequencyLayer output stays in LDS on the fused path (BSAREC_BUF_DSP is generic-path only)
     F.L = c.seq_len; F.Lp = p.Lp; F.cb = c.cutoff_bins; F.heads = c.heads;
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);

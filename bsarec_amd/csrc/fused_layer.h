@@ -398,12 +398,15 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
             } else if (ch == 0) qkv(std::integral_constant<int, 1>{});
             lds_barrier();
         }
-        if (grp == 0) {                              // low-pass, beta^2 high-pass, dropout, residual, LayerNorm -> sD
+        if (grp == 1) qkv(std::integral_constant<int, 2>{});
+        // low-pass, beta^2 high-pass, dropout, residual, LayerNorm -> sD: group 0 takes rows 0..47 while group 1 is
+        // still on the V projection, group 1 takes rows 48..63 afterwards
+        {
             f32x4 b2 = gld4(R2_sqrt_beta + lc);
             b2 = b2 * b2;
             const f32x4 g = gld4(R2_f_g + lc), be = gld4(R2_f_b + lc);
-#pragma unroll
-            for (int r0 = 0; r0 < 64; r0 += 16) {
+            const int rbeg = grp == 0 ? 0 : 48, rend = grp == 0 ? 48 : 64;
+            for (int r0 = rbeg; r0 < rend; r0 += 16) {
                 const int t = r0 + lr;
                 const bool ok = t < L;
                 const long e = (tok0 + t) * 64 + lc;
@@ -428,8 +431,6 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
                 }
                 st4(sD + t * FS + lc, y);
             }
-        } else {
-            qkv(std::integral_constant<int, 2>{});
         }
     }
     // dense weights for phase 4 (this group's K half), held across the attention

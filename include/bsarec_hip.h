@@ -65,7 +65,7 @@ enum {
     BSAREC_BUF_LAYER_OUT = 0,  /* [B,L,d]   output of layer l-1 (l = 0: embedding output), l in [0, N] */
     BSAREC_BUF_LOGITS = 1,     /* [B,Vp]    full-catalogue logits, Vp = 4*ceil(V/4), pad columns = 0 */
     BSAREC_BUF_LOSS = 2,       /* [1]       mean cross-entropy */
-    BSAREC_BUF_DSP = 3,        /* [B,L,d]   FrequencyLayer output of layer l */
+    BSAREC_BUF_DSP = 3,        /* [B,L,d]   FrequencyLayer output of layer l (generic path only; stays on chip in the fused path) */
     BSAREC_BUF_HMIX = 4,       /* [B,L,d]   alpha*dsp + (1-alpha)*gsp of layer l */
     BSAREC_BUF_PROBS = 5,      /* [B,h,L,Lp] attention probabilities of layer l (before dropout) */
     BSAREC_BUF_DLAYER_IN = 6,  /* [B,L,d]   gradient w.r.t. layer output l (ping-pong pair: only l = 0, 1 survive backward) */
