@@ -126,5 +126,15 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every global store
+// still in flight (the activations saved for backward) would have to be acknowledged at each of the ~10 phase
+// boundaries.  Use it only where nothing written to global memory before the barrier is read back by another wave after it;
+// it also lets global LOADS stay in flight across the barrier (software prefetch).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }

@@ -68,16 +68,6 @@ __device__ __forceinline__ float gld(const float* p) { return *(const AS_GLOBAL 
 __device__ __forceinline__ void gst(float* p, float v) { *(AS_GLOBAL float*)p = v; }
 __device__ __forceinline__ int gldi(const int* p) { return *(const AS_GLOBAL int*)p; }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): every global store
-// still in flight (the activations saved for backward) would have to be acknowledged at each of the ~10 phase
-// boundaries.  Nothing written to global memory in these kernels is read back inside them, so only the LDS
-// counter has to drain before the barrier.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
 // acc += A(rows from LDS) . W^T(rows from global), K = 8*NKB.  sa / gw already point at this lane's row + 4*half.

@@ -174,26 +174,19 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float bsum = 0.f;
 
-    TileLoader<BM, A_KM, AXF> la;
-    TileLoader<BN, B_KM, BXF> lb;
-    auto issue = [&](int it) {
+    // Two register stages per operand: tile it+2 is requested while tile it is multiplied and tile it+1 waits in
+    // registers for its turn to be written to LDS, so a global/L2 round trip has two whole k-steps to land (one
+    // k-step of a 64x64 tile is only 16 MFMAs per wave -- shorter than the round trip).
+    TileLoader<BM, A_KM, AXF> la0, la1;
+    TileLoader<BN, B_KM, BXF> lb0, lb1;
+    auto issue = [&](int it, TileLoader<BM, A_KM, AXF>& la, TileLoader<BN, B_KM, BXF>& lb) {
         const int seg = (P.nseg > 1) ? it / ktiles : prob;
         const int kt = (P.nseg > 1) ? it % ktiles : it;
         const int k0 = kbeg + kt * BK;
         la.load(P.A[seg] + aoff, P.lda, ctx.m0, P.M, k0, A_KM ? kvend : kend, X, zb);
         lb.load(P.B[seg] + boff, P.ldb, ctx.n0, P.Nb, k0, B_KM ? kvend : kend, X, zb);
     };
-
-    if (nit > 0) {
-        issue(0);
-        la.store(As0);
-        lb.store(Bs0);
-    }
-    __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-        const float* as = (it & 1) ? As1 : As0;
-        const float* bs = (it & 1) ? Bs1 : Bs0;
-        if (it + 1 < nit) issue(it + 1);
+    auto compute = [&](const float* __restrict__ as, const float* __restrict__ bs) {
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
             f32x4 af[TM], bf[TN];
@@ -227,11 +220,24 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
 #pragma unroll 8
             for (int k = 0; k < BK; ++k) bsum += as[k * LDAS + tid];
         }
-        if (it + 1 < nit) {
-            la.store((it & 1) ? As0 : As1);
-            lb.store((it & 1) ? Bs0 : Bs1);
-        }
-        __syncthreads();
+    };
+
+    if (nit > 0) issue(0, la0, lb0);
+    if (nit > 1) issue(1, la1, lb1);
+    if (nit > 0) { la0.store(As0); lb0.store(Bs0); }
+    lds_barrier();       // LDS-only: the prefetched global loads stay in flight
+    for (int it = 0; it < nit; it += 2) {
+        // even step: LDS buffer 0 = tile it, stage 1 = tile it+1, stage 0 is free
+        if (it + 2 < nit) issue(it + 2, la0, lb0);
+        compute(As0, Bs0);
+        if (it + 1 < nit) { la1.store(As1); lb1.store(Bs1); }
+        lds_barrier();       // LDS-only: the prefetched global loads stay in flight
+        if (it + 1 >= nit) break;
+        // odd step: LDS buffer 1 = tile it+1, stage 0 = tile it+2, stage 1 is free
+        if (it + 3 < nit) issue(it + 3, la1, lb1);
+        compute(As1, Bs1);
+        if (it + 2 < nit) { la0.store(As0); lb0.store(Bs0); }
+        lds_barrier();       // LDS-only: the prefetched global loads stay in flight
     }
     if (BGRAD && A_KM && by == 0 && tid < BM && ctx.m0 + tid < P.M)
         bgrad[((long)prob * P.nsplit + split) * P.M + ctx.m0 + tid] = bsum;

@@ -405,6 +405,14 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
         for (int i = threadIdx.x; i < CHUNK; i += ROW_THREADS) sid[i] = i < n ? ids32[t0 + i] : 0;
         for (int i = threadIdx.x; i < SCATTER_FLOATS / 4; i += ROW_THREADS) st4(acc + 4 * i, f32x4{0, 0, 0, 0});
         __syncthreads();
+        constexpr int NP = CHUNK / RPP;                   // rows per thread group, loads issued together
+        f32x4 g[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int j = lr + p * RPP;
+            g[p] = f32x4{0, 0, 0, 0};
+            if (colok && j < n && sid[j] != 0) g[p] = ld4(de + (long)(t0 + j) * d + lc);
+        }
         for (int j = threadIdx.x; j < CHUNK; j += ROW_THREADS) {      // first occurrence of sid[j]: 4 ids per LDS read,
             const int id = sid[j];                                    // no early exit (independent, pipelined reads)
             int l = j;
@@ -418,14 +426,6 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
             lead[j] = l;
         }
         __syncthreads();
-        constexpr int NP = CHUNK / RPP;                   // rows per thread group, loads issued together
-        f32x4 g[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int j = lr + p * RPP;
-            g[p] = f32x4{0, 0, 0, 0};
-            if (colok && j < n && sid[j] != 0) g[p] = ld4(de + (long)(t0 + j) * d + lc);
-        }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int j = lr + p * RPP;
