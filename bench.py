@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp", action="store_true", help="take the data-parallel step (RCCL all-reduce) even with one rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,8 +90,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    if world > 1 or a.dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = torch.distributed.group.WORLD
 
@@ -125,39 +127,11 @@ def main():
         cursor.zero_()
         perm_state["pos"] = 0
 
-    def step_body():
-        if pg is None:
-            return model.train_step_indexed(batches.inputs, batches.answers, perm_buf, cursor, B)
-        plan = model._plan(B)
-        if not hasattr(plan, "ids_buf"):
-            plan.ids_buf = torch.zeros((B, a.seq_len), dtype=torch.int64, device=dev)
-            plan.ans_buf = torch.zeros((B,), dtype=torch.int64, device=dev)
-        Lb.check(plan.lib.bsarec_gather_batch(batches.inputs.data_ptr(), batches.answers.data_ptr(), perm_buf.data_ptr(),
-                                              perm_buf.shape[0], cursor.data_ptr(), B, a.seq_len, plan.ids_buf.data_ptr(),
-                                              plan.ans_buf.data_ptr(), model._stream()), "bsarec_gather_batch")
-        cursor.add_(B)
-        return trainer._step_eager(plan.ids_buf, plan.ans_buf)
-
-    graph_box = {}
-
     def one_step():
         if perm_state["pos"] + B > n_local[0]:
             new_epoch()
         perm_state["pos"] += B
-        if use_graph:
-            if "g" not in graph_box:
-                model._plan(B)
-                loss0 = step_body()                         # eager: creates static buffers, sets kernel attributes
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    graph_box["loss"] = step_body()
-                graph_box["g"] = g
-                perm_state["pos"] += B
-                g.replay()
-                return graph_box["loss"]
-            graph_box["g"].replay()
-            return graph_box["loss"]
-        return step_body()
+        return trainer.indexed_step(batches, perm_buf, cursor, None)
 
     def stream_batches():
         while True:
@@ -167,7 +141,7 @@ def main():
     stream = stream_batches()
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
@@ -263,7 +237,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

@@ -65,6 +65,7 @@ EXPORTS = {
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_train_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 7 + [C.c_long] + [C.c_float] * 5 +
                                   [C.c_void_p]),
+    "bsarec_grad_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 4),
     "bsarec_freq_layer_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_int,
                                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_freq_layer_bwd_scratch_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),

@@ -831,6 +831,19 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
     return bsarec_adam_step(params_flat, grads_flat, m, v, n, p->state, lr, b1, b2, eps, wd, 1.0f, stream);
 }
 
+extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, const int64_t* answers_table,
+                                        const int64_t* perm, long n_samples, void* cursor, int64_t* ids_buf,
+                                        int64_t* answers_buf, void* stream) {
+    if (!p) return -10;
+    RET(bsarec_gather_batch(table, answers_table, perm, n_samples, cursor, p->cfg.batch, p->cfg.seq_len, ids_buf,
+                            answers_buf, stream));
+    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state, (long long*)cursor, p->cfg.batch);
+    HIPCHK(hipGetLastError());
+    RET(bsarec_forward(p, ids_buf, 1, stream));
+    RET(bsarec_loss(p, answers_buf, stream));
+    return bsarec_backward(p, stream);
+}
+
 extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int64_t* answers, float* params_flat,
                                  const float* grads_flat, float* m, float* v, long n, float lr, float b1, float b2,
                                  float eps, float wd, void* stream) {

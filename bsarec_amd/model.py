@@ -338,6 +338,19 @@ class BSARecModel(nn.Module):
             self._stream()), "bsarec_train_step_indexed")
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
+    def grad_step_indexed(self, table, answers_table, perm, cursor, batch: int) -> torch.Tensor:
+        """Data-parallel half of train_step_indexed: gather + forward + loss + backward into the gradient arena
+        (no Adam).  Follow with an all-reduce of ``_garena`` and :meth:`adam_step`."""
+        plan = self._plan(batch)
+        if not hasattr(plan, "ids_buf"):
+            dev = self._arena.device
+            plan.ids_buf = torch.zeros((batch, self.args.max_seq_length), dtype=torch.int64, device=dev)
+            plan.ans_buf = torch.zeros((batch,), dtype=torch.int64, device=dev)
+        L.check(plan.lib.bsarec_grad_step_indexed(
+            plan.handle, table.data_ptr(), answers_table.data_ptr(), perm.data_ptr(), perm.shape[0], cursor.data_ptr(),
+            plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), self._stream()), "bsarec_grad_step_indexed")
+        return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
     def adam_step(self, grad_scale: float = 1.0):
         """Fused Adam over the flat arenas (after an external gradient all-reduce)."""
         a = self._adam

@@ -52,7 +52,7 @@ class Trainer:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.dp = process_group is not None            # data-parallel step (all-reduce), even for a 1-rank group
-        self.use_graph = use_graph and not self.dp
+        self.use_graph = use_graph                       # data parallel: two graphs around the eager all-reduce
         self._graphs = {}
         self._seen_cache = {}
 
@@ -132,10 +132,60 @@ class Trainer:
         graph.replay()
         return loss
 
-    def _epoch_indexed(self, dl: DeviceBatches):
-        """One epoch straight off the device-resident sample table: per step ONE C call (gather + forward +
-        loss + backward + Adam), replayed from a hipGraph when single-GPU; no per-step host tensor work."""
+    def indexed_step(self, dl: DeviceBatches, pbuf: torch.Tensor, cursor: torch.Tensor, loss_sum: Optional[torch.Tensor]):
+        """One optimisation step straight off the device-resident sample table (the batch at ``cursor`` in the
+        permutation ``pbuf``; the cursor advances on the device).  Single GPU: ONE captured graph (gather + forward +
+        CE + backward + Adam).  Data parallel: graph A (gather + forward + CE + backward), the summing all-reduce of the
+        flat gradient arena (RCCL, eager), graph B (Adam on sum / world)."""
         m, B = self.model, dl.batch_size
+        key = ("indexed", B, pbuf.data_ptr(), pbuf.shape[0], cursor.data_ptr(), None if loss_sum is None else loss_sum.data_ptr())
+
+        def grad_part():
+            if not self.dp:
+                loss = m.train_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B)
+            else:
+                loss = m.grad_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B)
+            if loss_sum is not None:
+                loss_sum.add_(loss)
+            return loss
+
+        def adam_part():
+            m.adam_step(grad_scale=1.0 / self.world)
+
+        if not self.use_graph:
+            loss = grad_part()
+            if self.dp:
+                allreduce_sum_(m._garena, self.pg)
+                adam_part()
+            return loss
+        g = self._graphs.get(key)
+        if g is None:
+            m._plan(B)
+            loss = grad_part()                                # eager first step: static buffers, kernel attributes
+            if self.dp:
+                allreduce_sum_(m._garena, self.pg)
+                adam_part()
+            torch.cuda.synchronize()
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                gloss = grad_part()
+            gb = None
+            if self.dp:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb):
+                    adam_part()
+            self._graphs[key] = (ga, gb, gloss)
+            return loss
+        ga, gb, gloss = g
+        ga.replay()
+        if self.dp:
+            allreduce_sum_(m._garena, self.pg)
+            gb.replay()
+        return gloss
+
+    def _epoch_indexed(self, dl: DeviceBatches):
+        """One epoch off the device-resident sample table; no per-step host tensor work."""
+        B = dl.batch_size
         perm = dl.local_permutation()
         dl.epoch += 1
         n = perm.shape[0]
@@ -148,43 +198,8 @@ class Trainer:
         pbuf = self._perm_buf[:n]
         self._cursor.zero_()
         self._loss_sum.zero_()
-
-        def body():
-            if not self.dp:
-                loss = m.train_step_indexed(dl.inputs, dl.answers, pbuf, self._cursor, B)
-            else:
-                plan = m._plan(B)
-                if not hasattr(plan, "ids_buf"):
-                    plan.ids_buf = torch.zeros((B, self.args.max_seq_length), dtype=torch.int64, device=self.device)
-                    plan.ans_buf = torch.zeros((B,), dtype=torch.int64, device=self.device)
-                from . import _lib as L
-                L.check(plan.lib.bsarec_gather_batch(dl.inputs.data_ptr(), dl.answers.data_ptr(), pbuf.data_ptr(), n,
-                                                     self._cursor.data_ptr(), B, self.args.max_seq_length,
-                                                     plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), m._stream()),
-                        "bsarec_gather_batch")
-                self._cursor += B
-                loss = self._step_eager(plan.ids_buf, plan.ans_buf)
-            self._loss_sum += loss
-
-        if nfull:
-            if self.use_graph:
-                key = ("indexed", B, n)
-                if key not in self._graphs:
-                    m._plan(B)
-                    body()                                  # eager first step also creates the static buffers
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        body()
-                    self._graphs[key] = graph
-                    done = 1
-                else:
-                    done = 0
-                graph = self._graphs[key]
-                for _ in range(nfull - done):
-                    graph.replay()
-            else:
-                for _ in range(nfull):
-                    body()
+        for _ in range(nfull):
+            self.indexed_step(dl, pbuf, self._cursor, self._loss_sum)
         nb = nfull
         if tail:                                            # short last batch (single GPU only): its own plan, eager
             idx = perm[nfull * B:]
@@ -212,7 +227,7 @@ class Trainer:
             for batch in dataloader:
                 batch = tuple(t.to(self.device, non_blocking=True) for t in batch)
                 _, input_ids, answers, _, _ = batch
-                if self.use_graph:
+                if self.use_graph and not self.dp:
                     B = input_ids.shape[0]
                     first = B not in self._graphs
                     loss = self._step_graph(input_ids, answers)

@@ -142,6 +142,12 @@ int bsarec_train_step_indexed(bsarec_plan_t *plan, const int64_t *table, const i
                               float *params_flat, const float *grads_flat, float *exp_avg, float *exp_avg_sq, long n,
                               float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
 
+/* The data-parallel half of the above: gather + forward + loss + backward (no Adam).  The caller then all-reduces the
+ * flat gradient arena (RCCL) and calls bsarec_adam_step(grad_scale = 1/world). */
+int bsarec_grad_step_indexed(bsarec_plan_t *plan, const int64_t *table, const int64_t *answers_table,
+                             const int64_t *perm, long n_samples, void *cursor, int64_t *ids_buf, int64_t *answers_buf,
+                             void *stream);
+
 /* Stand-alone FrequencyLayer (src/model/bsarec.py:90-104) for per-op parity tests:
  * y = LN(Drop(low + beta^2 (x - low)) + x); backward given dy. */
 int bsarec_freq_layer_fwd(const float *x, const float *sqrt_beta, const float *ln_w, const float *ln_b,

@@ -239,18 +239,19 @@ def test_data_parallel_step_one_rank_rccl_equals_single_gpu_step():
         u, x, a_ = D.train_table(seqs, 50)
         u, x, a_ = u[:768], x[:768], a_[:768]
         res = {}
-        for mode in ("single", "dp"):
+        for mode in ("single", "dp", "dp_graph"):
             torch.manual_seed(1)
             model = BSARecModel(ns(item_size=301)).cuda()
             model.set_seed(5)
             dl = D.DeviceBatches(u, x, a_, 256, "cuda", shuffle=True, seed=11)
-            tr = Trainer(model, dl, None, None, ns(item_size=301), None, use_graph=False,
-                         process_group=dist.group.WORLD if mode == "dp" else None)
+            tr = Trainer(model, dl, None, None, ns(item_size=301), None, use_graph=(mode == "dp_graph"),
+                         process_group=dist.group.WORLD if mode != "single" else None)
             losses = [float(tr.train(e)["rec_loss"]) for e in range(2)]
             res[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
-        assert res["single"][0] == res["dp"][0]
-        for k in res["single"][1]:
-            np.testing.assert_allclose(res["single"][1][k], res["dp"][1][k], atol=2e-6, err_msg=k)
+        for mode in ("dp", "dp_graph"):       # "dp_graph": graph A (grad step) + eager all-reduce + graph B (Adam)
+            assert res["single"][0] == res[mode][0]
+            for k in res["single"][1]:
+                np.testing.assert_allclose(res["single"][1][k], res[mode][1][k], atol=2e-6, err_msg=k)
     finally:
         dist.destroy_process_group()
 
