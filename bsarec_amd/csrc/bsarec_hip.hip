@@ -739,9 +739,19 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
                 {p->dv, d, X, d, d, d, sm.wv, sm.bv, 0},        {p->dO, d, b.ctx, d, d, d, sm.wo, sm.bo, 0},
                 {p->dU, 4 * d, b.hmix, d, 4 * d, d, sm.w1, sm.b1, 0}, {p->dT, d, b.u, 4 * d, d, 4 * d, sm.w2, sm.b2, 1}};
             int tiles = 0;
+            // Top block: only position L-1 of each sequence carries an upstream gradient (bsarec.py:32), so dq, dO, dU
+            // and dT2 are zero on every other row: their four products reduce over the B last positions only
+            // (row stride L*ld), exactly; dk and dv still reduce over all tokens.
+            const bool top = (l == N - 1);
             for (int i = 0; i < 6; ++i) {
-                GemmP g = gemm_defaults(sp[i].M, sp[i].N, T);
+                const bool last_only = top && i != 1 && i != 2;
+                GemmP g = gemm_defaults(sp[i].M, sp[i].N, last_only ? B : T);
                 g.lda = sp[i].lda; g.ldb = sp[i].ldb; g.A[0] = sp[i].A; g.B[0] = sp[i].B; g.nsplit = ns; g.kchunk = p->kchunk;
+                if (last_only) {
+                    g.A[0] += (long)(L - 1) * sp[i].lda; g.B[0] += (long)(L - 1) * sp[i].ldb;
+                    g.lda *= L; g.ldb *= L;
+                    g.kchunk = (int)rup(cdiv(B, ns), GEMM_BK);           // slices beyond ceil(B / kchunk) write zero slabs
+                }
                 G.P[i] = g;
                 G.E[i] = epi_linear<false, false, false>(slab_w_ptr(*p, sp[i].woff), sp[i].N);
                 G.E[i].c_split = (long)sp[i].M * sp[i].N;

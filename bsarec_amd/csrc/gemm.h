@@ -162,7 +162,7 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
     int kbeg = 0, kend = P.K;
     if (P.nsplit > 1) { kbeg = split * P.kchunk; kend = min(P.K, kbeg + P.kchunk); }
     const int kvend = min(kend, P.Kv);
-    const int ktiles = (kend - kbeg + BK - 1) / BK;
+    const int ktiles = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
     const int nit = ktiles * P.nseg;
 
     f32x16 acc[TM][TN];
