@@ -577,7 +577,7 @@ extern "C" int bsarec_logits(bsarec_plan_t* p, void* stream) {
     return launch_gemm<64, 64, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, no_xform(), e, nullptr, 1, s, BSAREC_K_LOGITS);
 }
 
-extern "C" int bsarec_loss(bsarec_plan_t* p, const int64_t* answers, void* stream) {
+static int loss_impl(bsarec_plan_t* p, const int64_t* answers, void* stream, bool with_mean) {
     if (!p || !answers) return -10;
     hipStream_t s = (hipStream_t)stream;
     RET(bsarec_logits(p, stream));
@@ -585,9 +585,11 @@ extern "C" int bsarec_loss(bsarec_plan_t* p, const int64_t* answers, void* strea
     LAUNCH(ce_rows_kernel, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, c.item_size, p->Vp,
                        1.0f / (float)c.batch, p->dlogits, p->loss_rows);
     HIPCHK(hipGetLastError());
-    LAUNCH(loss_mean_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->loss_rows, c.batch, p->loss);
+    if (with_mean) LAUNCH(loss_mean_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->loss_rows, c.batch, p->loss);
     return (int)hipGetLastError();
 }
+
+extern "C" int bsarec_loss(bsarec_plan_t* p, const int64_t* answers, void* stream) { return loss_impl(p, answers, stream, true); }
 
 // ---------------------------------------------------------------------------------------------
 // backward
@@ -804,18 +806,29 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // Adam / fused step
 // ---------------------------------------------------------------------------------------------
+static int launch_adam_tick(void* state, float lr, float b1, float b2, const float* loss_rows, int B, float* loss_out,
+                            void* cursor, int advance, int bump_step, hipStream_t s) {
+    LAUNCH(adam_tick_kernel, dim3(1), dim3(ROW_THREADS), 0, s, (uint64_t*)state, (double)lr, (double)b1, (double)b2, loss_rows, B,
+           loss_out, (long long*)cursor, advance, bump_step);
+    return (int)hipGetLastError();
+}
+
+static int adam_launch(float* params, const float* grads, float* m, float* v, long n, void* state, float b1, float b2,
+                       float eps, float wd, float gscale, hipStream_t s) {
+    const long n4 = n / 4;
+    int blocks = cdiv(n4, ROW_THREADS);
+    if (blocks > 2048) blocks = 2048;
+    LAUNCH(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, params, grads, m, v, n4, (const uint64_t*)state, b1, b2, eps, wd,
+           gscale);
+    return (int)hipGetLastError();
+}
+
 extern "C" int bsarec_adam_step(float* params, const float* grads, float* m, float* v, long n, void* state, float lr,
                                 float b1, float b2, float eps, float wd, float gscale, void* stream) {
     if (!params || !grads || !m || !v || !state || n <= 0 || (n & 3)) return -10;
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH(adam_tick_kernel, dim3(1), dim3(1), 0, s, (uint64_t*)state, (double)lr, (double)b1, (double)b2);
-    HIPCHK(hipGetLastError());
-    const long n4 = n / 4;
-    int blocks = cdiv(n4, ROW_THREADS);
-    if (blocks > 2048) blocks = 2048;
-    LAUNCH(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, params, grads, m, v, n4, (const uint64_t*)state,
-                       b1, b2, eps, wd, gscale);
-    return (int)hipGetLastError();
+    RET(launch_adam_tick(state, lr, b1, b2, nullptr, 0, nullptr, nullptr, 0, 0, s));
+    return adam_launch(params, grads, m, v, n, state, b1, b2, eps, wd, gscale, s);
 }
 
 extern "C" int bsarec_gather_batch(const int64_t* table, const int64_t* answers_table, const int64_t* perm, long n_samples,
@@ -830,15 +843,16 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
                                          const int64_t* perm, long n_samples, void* cursor, int64_t* ids_buf,
                                          int64_t* answers_buf, float* params_flat, const float* grads_flat, float* m,
                                          float* v, long n, float lr, float b1, float b2, float eps, float wd, void* stream) {
-    if (!p) return -10;
+    if (!p || !params_flat || !grads_flat || !m || !v || n <= 0 || (n & 3)) return -10;
+    hipStream_t s = (hipStream_t)stream;
     RET(bsarec_gather_batch(table, answers_table, perm, n_samples, cursor, p->cfg.batch, p->cfg.seq_len, ids_buf,
                             answers_buf, stream));
-    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state, (long long*)cursor, p->cfg.batch);
-    HIPCHK(hipGetLastError());
     RET(bsarec_forward(p, ids_buf, 1, stream));
-    RET(bsarec_loss(p, answers_buf, stream));
+    RET(loss_impl(p, answers_buf, stream, false));
     RET(bsarec_backward(p, stream));
-    return bsarec_adam_step(params_flat, grads_flat, m, v, n, p->state, lr, b1, b2, eps, wd, 1.0f, stream);
+    // the Adam tick closes the step: mean loss, Adam t and bias corrections, next forward-step index, cursor += B
+    RET(launch_adam_tick(p->state, lr, b1, b2, p->loss_rows, p->cfg.batch, p->loss, cursor, p->cfg.batch, 1, s));
+    return adam_launch(params_flat, grads_flat, m, v, n, p->state, b1, b2, eps, wd, 1.0f, s);
 }
 
 extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, const int64_t* answers_table,
@@ -847,11 +861,12 @@ extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, 
     if (!p) return -10;
     RET(bsarec_gather_batch(table, answers_table, perm, n_samples, cursor, p->cfg.batch, p->cfg.seq_len, ids_buf,
                             answers_buf, stream));
-    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state, (long long*)cursor, p->cfg.batch);
-    HIPCHK(hipGetLastError());
     RET(bsarec_forward(p, ids_buf, 1, stream));
     RET(bsarec_loss(p, answers_buf, stream));
-    return bsarec_backward(p, stream);
+    RET(bsarec_backward(p, stream));
+    // same convention as bsarec_train_step_indexed: the step index / cursor advance when the step is done
+    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state, (long long*)cursor, p->cfg.batch);
+    return (int)hipGetLastError();
 }
 
 extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int64_t* answers, float* params_flat,

@@ -530,12 +530,32 @@ gather_batch_kernel(const int64_t* __restrict__ table, const int64_t* __restrict
     }
 }
 
-__global__ void adam_tick_kernel(uint64_t* state, double lr, double b1, double b2) {
-    const uint64_t t = state[2] + 1;
-    state[2] = t;
-    float* f = reinterpret_cast<float*>(state + 3);
-    f[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
-    f[1] = (float)sqrt(1.0 - pow(b2, (double)t));
+// One 256-thread block: advances Adam's t and publishes the bias corrections; in the fused single-GPU step it also
+// closes the step: mean loss of the batch, forward-step counter (next dropout masks) and batch cursor.
+__global__ void __launch_bounds__(ROW_THREADS)
+adam_tick_kernel(uint64_t* state, double lr, double b1, double b2, const float* __restrict__ loss_rows, int B,
+                 float* __restrict__ loss_out, long long* cursor, int advance, int bump_step) {
+    __shared__ float red[ROW_THREADS];
+    if (loss_rows) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < B; i += ROW_THREADS) s += loss_rows[i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = ROW_THREADS / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (loss_rows) loss_out[0] = red[0] / (float)B;
+        const uint64_t t = state[2] + 1;
+        state[2] = t;
+        float* f = reinterpret_cast<float*>(state + 3);
+        f[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
+        f[1] = (float)sqrt(1.0 - pow(b2, (double)t));
+        if (bump_step) state[1] += 1;
+        if (cursor) *cursor += advance;
+    }
 }
 
 // K9 fused Adam over the flat parameter arena (torch.optim.Adam semantics, src/trainers.py:27-28):

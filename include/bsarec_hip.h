@@ -135,8 +135,9 @@ int bsarec_train_step(bsarec_plan_t *plan, const int64_t *ids, const int64_t *an
 int bsarec_gather_batch(const int64_t *table, const int64_t *answers_table, const int64_t *perm, long n_samples,
                         const void *cursor, int B, int L, int64_t *ids_out, int64_t *answers_out, void *stream);
 
-/* bsarec_train_step fed from the resident table: gather the batch at *cursor, advance *cursor by B, then
- * forward + loss + backward + Adam.  A captured graph of this call replays a whole epoch with no host work. */
+/* bsarec_train_step fed from the resident table: gather the batch at *cursor, forward + loss + backward + Adam; the
+ * Adam tick closes the step (mean loss, forward-step index += 1, *cursor += B).  A captured graph of this call
+ * replays a whole epoch with no host work. */
 int bsarec_train_step_indexed(bsarec_plan_t *plan, const int64_t *table, const int64_t *answers_table,
                               const int64_t *perm, long n_samples, void *cursor, int64_t *ids_buf, int64_t *answers_buf,
                               float *params_flat, const float *grads_flat, float *exp_avg, float *exp_avg_sq, long n,
