@@ -438,11 +438,16 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
         // one leader row per wave-instruction: lane = column, so every global_atomic_add_f32 covers 256 contiguous
         // bytes (the full-rate shape; 4-byte pieces at a 16-byte stride run ~17x slower)
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        for (int j = wv; j < n; j += ROW_THREADS / 64) {
-            const int id = sid[j];
-            if (id == 0 || lead[j] != j) continue;        // wave-uniform
+        constexpr int PW = CHUNK / (ROW_THREADS / 64);      // tokens owned by one wave (<= 64)
+        const int j0 = wv * PW, myj = j0 + lane;
+        const bool is_leader = lane < PW && myj < n && sid[myj] != 0 && lead[myj] == myj;
+        unsigned long long todo = __ballot(is_leader);      // wave-uniform work list: no per-token LDS round trips
+        while (todo) {
+            const int j = j0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const long row = (long)sid[j] * d;
             for (int c0 = 0; c0 < d; c0 += 64)
-                if (c0 + lane < d) unsafeAtomicAdd(dE + (long)id * d + c0 + lane, acc[j * W + c0 + lane]);
+                if (c0 + lane < d) unsafeAtomicAdd(dE + row + c0 + lane, acc[j * W + c0 + lane]);
         }
         return;
     }
