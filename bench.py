@@ -170,7 +170,9 @@ def main():
                                f"{a.layers} BSARec layers, {a.heads} heads, c=3 alpha=0.9 dropout=0.5, Adam lr=1e-3; "
                                "fwd + full-catalogue CE + bwd + Adam per step",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq_len,
-                   "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
+                   "parallelism": f"dp{world}", "launch": ("hipGraph replay" if use_graph else "eager") +
+                             (f" ({trainer.dp_graph} graph per step incl. RCCL all-reduce)" if pg is not None and use_graph and trainer.dp_graph == "one"
+                              else " (grad graph + eager RCCL all-reduce + Adam graph)" if pg is not None and use_graph else ""),
                    "final_loss": round(final_loss, 4)},
     }
     flops_seq = train_flops_per_seq(a)
@@ -194,6 +196,9 @@ def main():
             cands = [(Lb.K_FFN1, "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)", 2.0 * T * d * 4 * d),
                      (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d)]
         rows = []
+        ovh = C.c_double()
+        lib.bsarec_profile_event_overhead(C.c_void_p(torch.cuda.current_stream().cuda_stream), 200, C.byref(ovh))
+        ovh_s = ovh.value * 1e-3          # an empty event bracket: what the two marker packets themselves cost
         for kclass, name, fl in cands:
             lib.bsarec_profile_select(kclass)
             nprof = 10
@@ -205,9 +210,9 @@ def main():
             lib.bsarec_profile_read(C.byref(ms), C.byref(n))
             if n.value == 0:
                 continue
-            avg_s = ms.value * 1e-3 / n.value
+            avg_s = ms.value * 1e-3 / n.value - ovh_s
             rows.append({"kernel": name, "launches_per_step": n.value / nprof, "avg_us": round(avg_s * 1e6, 3),
-                         "us_per_step": round(ms.value * 1e3 / nprof, 2), "flops_per_launch": float(fl),
+                         "us_per_step": round(avg_s * 1e6 * n.value / nprof, 2), "flops_per_launch": float(fl),
                          "achieved": round(fl / avg_s / 1e12, 3)})
         lib.bsarec_profile_select(Lb.K_NONE)
         rows.sort(key=lambda r: -r["us_per_step"])
@@ -216,7 +221,7 @@ def main():
         def pmc_traffic(kernel_prefix):
             # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/): WRITE_SIZE + 2 * FETCH_SIZE KiB
             # (gfx950 tallies wide streaming reads at half their bytes, MI355X guide, HBM section)
-            path = os.path.join(ROOT, "profiles", "r01_b_pmc_C1_fused.csv")
+            path = os.path.join(ROOT, "profiles", "r01_c_pmc_C1.csv")
             if not os.path.exists(path) or not fused or a.batch != 256:
                 return None
             vals = {}
@@ -231,7 +236,7 @@ def main():
                            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(top["achieved"] / FP32_MFMA_PEAK_TFLOPS, 5),
                            "traffic": pmc_traffic(top["kernel"].split(" ")[0]),
-                           "avg_us": top["avg_us"], "launches_per_step": top["launches_per_step"],
+                           "avg_us": top["avg_us"], "event_overhead_us": round(ovh_s * 1e6, 3), "launches_per_step": top["launches_per_step"],
                            "flops_per_launch": top["flops_per_launch"], "other_kernels": rows[1:]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)

@@ -75,6 +75,7 @@ EXPORTS = {
     "bsarec_set_fused": (C.c_int, [C.c_int]),
     "bsarec_debug_stamps": (C.c_int, [C.c_void_p]),
     "bsarec_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "bsarec_profile_event_overhead": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -953,3 +953,20 @@ extern "C" int bsarec_profile_read(double* ms_total, int* launches) {
     g_prof_used = 0;
     return 0;
 }
+
+extern "C" int bsarec_profile_event_overhead(void* stream, int reps, double* ms_avg) {
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    double tot = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        HIPCHK(hipEventRecord(a, s)); HIPCHK(hipEventRecord(b, s));
+        HIPCHK(hipEventSynchronize(b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        tot += ms;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (ms_avg) *ms_avg = reps > 0 ? tot / reps : 0.0;
+    return 0;
+}

@@ -18,10 +18,11 @@ def shard_of_global_batch(index: torch.Tensor, batch_size: int, rank: int, world
     return index[rank * batch_size:(rank + 1) * batch_size]
 
 
-def allreduce_sum_(flat_grads: torch.Tensor, group=None) -> float:
+def allreduce_sum_(flat_grads: torch.Tensor, group=None, force: bool = False) -> float:
     """In-place summing all-reduce of the flat gradient arena; returns the scale (1/world) that the
-    fused Adam applies to the sum."""
+    fused Adam applies to the sum.  ``force`` issues the collective even in a 1-rank group (tests, bench --dp:
+    exercises the RCCL launch and its graph capture on a single GPU)."""
     world = torch.distributed.get_world_size(group)
-    if world > 1:
+    if world > 1 or force:
         torch.distributed.all_reduce(flat_grads, op=torch.distributed.ReduceOp.SUM, group=group)
     return 1.0 / world

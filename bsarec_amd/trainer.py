@@ -9,6 +9,7 @@ evaluation branch scores, masks seen items and takes the top-20 on the GPU.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -52,6 +53,7 @@ class Trainer:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.dp = process_group is not None            # data-parallel step (all-reduce), even for a 1-rank group
+        self.dp_graph = os.environ.get("BSAREC_DP_GRAPH", "one")
         self.use_graph = use_graph                       # data parallel: two graphs around the eager all-reduce
         self._graphs = {}
         self._seen_cache = {}
@@ -105,7 +107,7 @@ class Trainer:
         plan = m._run_forward(ids, train=True, new_step=True)
         m._run_loss(plan, ans)
         m._run_backward(plan)
-        scale = allreduce_sum_(m._garena, self.pg)
+        scale = allreduce_sum_(m._garena, self.pg, force=True)
         m.adam_step(grad_scale=scale)
         from . import _lib as L
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
@@ -136,7 +138,9 @@ class Trainer:
         """One optimisation step straight off the device-resident sample table (the batch at ``cursor`` in the
         permutation ``pbuf``; the cursor advances on the device).  Single GPU: ONE captured graph (gather + forward +
         CE + backward + Adam).  Data parallel: graph A (gather + forward + CE + backward), the summing all-reduce of the
-        flat gradient arena (RCCL, eager), graph B (Adam on sum / world)."""
+        flat gradient arena (RCCL), Adam on sum / world -- captured as ONE graph with the collective inside it
+        (``dp_graph="one"``, default), or as graph A + eager all-reduce + graph B (``"two"``; also the fallback when the
+        capture of the collective is refused).  Env BSAREC_DP_GRAPH selects."""
         m, B = self.model, dl.batch_size
         key = ("indexed", B, pbuf.data_ptr(), pbuf.shape[0], cursor.data_ptr(), None if loss_sum is None else loss_sum.data_ptr())
 
@@ -152,34 +156,51 @@ class Trainer:
         def adam_part():
             m.adam_step(grad_scale=1.0 / self.world)
 
+        def exchange():
+            allreduce_sum_(m._garena, self.pg, force=True)
+
         if not self.use_graph:
             loss = grad_part()
             if self.dp:
-                allreduce_sum_(m._garena, self.pg)
+                exchange()
                 adam_part()
             return loss
         g = self._graphs.get(key)
         if g is None:
             m._plan(B)
-            loss = grad_part()                                # eager first step: static buffers, kernel attributes
-            if self.dp:
-                allreduce_sum_(m._garena, self.pg)
+            loss = grad_part()                                # eager first step: static buffers, kernel attributes,
+            if self.dp:                                       # RCCL communicator and its buffers
+                exchange()
                 adam_part()
             torch.cuda.synchronize()
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                gloss = grad_part()
-            gb = None
-            if self.dp:
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb):
-                    adam_part()
+            ga = gb = None
+            if self.dp and self.dp_graph == "one":
+                # the whole data-parallel step as ONE graph: RCCL's all-reduce kernel is captured between the
+                # gradient kernels and Adam, so a step costs one graph launch and no host round trip
+                try:
+                    ga = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga):
+                        gloss = grad_part()
+                        exchange()
+                        adam_part()
+                except Exception as e:                        # capture of the collective refused: two graphs instead
+                    self.logger.info(f"one-graph data-parallel capture failed ({type(e).__name__}: {e}); using two graphs")
+                    self.dp_graph, ga = "two", None
+                    torch.cuda.synchronize()
+            if ga is None:
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    gloss = grad_part()
+                if self.dp:
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb):
+                        adam_part()
             self._graphs[key] = (ga, gb, gloss)
             return loss
         ga, gb, gloss = g
         ga.replay()
-        if self.dp:
-            allreduce_sum_(m._garena, self.pg)
+        if gb is not None:
+            exchange()
             gb.replay()
         return gloss
 

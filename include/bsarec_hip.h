@@ -175,6 +175,9 @@ int bsarec_set_fused(int enable);
  * of the fused kernels (null disables). */
 int bsarec_debug_stamps(void *dev_buf);
 int bsarec_profile_read(double *ms_total, int *launches);
+/* Milliseconds one such hipEvent bracket reads with NO kernel inside it (average of `reps` back-to-back pairs on
+ * `stream`): the marker-packet cost bench.py subtracts so that its per-launch time agrees with rocprofv3's. */
+int bsarec_profile_event_overhead(void *stream, int reps, double *ms_avg);
 
 #ifdef __cplusplus
 }

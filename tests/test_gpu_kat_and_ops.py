@@ -242,16 +242,20 @@ def test_data_parallel_step_one_rank_rccl_equals_single_gpu_step():
         u, x, a_ = D.train_table(seqs, 50)
         u, x, a_ = u[:768], x[:768], a_[:768]
         res = {}
-        for mode in ("single", "dp", "dp_graph"):
+        for mode in ("single", "dp", "dp_graph", "dp_graph2"):
             torch.manual_seed(1)
             model = BSARecModel(ns(item_size=301)).cuda()
             model.set_seed(5)
             dl = D.DeviceBatches(u, x, a_, 256, "cuda", shuffle=True, seed=11)
-            tr = Trainer(model, dl, None, None, ns(item_size=301), None, use_graph=(mode == "dp_graph"),
+            tr = Trainer(model, dl, None, None, ns(item_size=301), None, use_graph=mode.startswith("dp_graph"),
                          process_group=dist.group.WORLD if mode != "single" else None)
+            tr.dp_graph = "two" if mode == "dp_graph2" else "one"
             losses = [float(tr.train(e)["rec_loss"]) for e in range(2)]
             res[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
-        for mode in ("dp", "dp_graph"):       # "dp_graph": graph A (grad step) + eager all-reduce + graph B (Adam)
+            if mode == "dp_graph":
+                assert tr.dp_graph == "one", "capture of the RCCL all-reduce inside the step graph was refused"
+        # "dp_graph": ONE graph with the RCCL all-reduce captured inside; "dp_graph2": graph A + eager all-reduce + graph B
+        for mode in ("dp", "dp_graph", "dp_graph2"):
             np.testing.assert_allclose(res["single"][0], res[mode][0], atol=2e-4)
             for k in res["single"][1]:
                 bad = np.abs(res["single"][1][k] - res[mode][1][k]) > 2e-5
