@@ -7,7 +7,8 @@ LIB_PATH = os.path.join(HERE, "libbsarec_hip.so")
 MAX_LAYERS = 16
 ABI_VERSION = 1
 
-(BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX) = range(9)
+(BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX,
+ BUF_DLOGITS) = range(10)
 K_NONE, K_FFN1, K_FFN2, K_QKV, K_LOGITS, K_DU, K_DW1, K_FUSED_FWD, K_FUSED_BWD = range(9)
 
 LAYER_FIELDS = ["sqrt_beta", "filter_ln_w", "filter_ln_b", "query_w", "query_b", "key_w", "key_b", "value_w", "value_b",

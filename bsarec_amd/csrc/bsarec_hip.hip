@@ -307,6 +307,7 @@ extern "C" long bsarec_buffer_offset(const bsarec_plan_t* p, int buffer, int lay
     switch (buffer) {
         case BSAREC_BUF_LAYER_OUT: if (layer < 0 || layer > N) return -1; ptr = p->X[layer]; break;
         case BSAREC_BUF_LOGITS: ptr = p->logits; break;
+        case BSAREC_BUF_DLOGITS: ptr = p->dlogits; break;
         case BSAREC_BUF_LOSS: ptr = p->loss; break;
         case BSAREC_BUF_LOSS_ROWS: ptr = p->loss_rows; break;
         case BSAREC_BUF_DSP: if (layer < 0 || layer >= N) return -1; ptr = p->lb[layer].dsp; break;

@@ -70,7 +70,8 @@ enum {
     BSAREC_BUF_PROBS = 5,      /* [B,h,L,Lp] attention probabilities of layer l (before dropout) */
     BSAREC_BUF_DLAYER_IN = 6,  /* [B,L,d]   gradient w.r.t. layer output l (ping-pong pair: only l = 0, 1 survive backward) */
     BSAREC_BUF_LOSS_ROWS = 7,  /* [B]       per-sequence cross-entropy */
-    BSAREC_BUF_CTX = 8         /* [B,L,d]   attention context of layer l */
+    BSAREC_BUF_CTX = 8,        /* [B,L,d]   attention context of layer l */
+    BSAREC_BUF_DLOGITS = 9     /* [B,Vp]    d loss / d logits = (softmax - onehot(answer)) / B, pad columns = 0 (after bsarec_loss) */
 };
 
 typedef struct bsarec_plan bsarec_plan_t;   /* host-side launch plan (no device memory of its own) */

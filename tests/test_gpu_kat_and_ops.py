@@ -227,6 +227,60 @@ def test_config4_shape_large_batch_and_catalogue_runs_and_learns():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
+def test_config5_scale_catalogue_ten_million_items_properties():
+    """BASELINE config 5's catalogue (V = 10,000,001; logits rows of 40 MB, B*V > 2^31 elements) through the same
+    entry points: the loss equals a float64 log-sum-exp recomputed from the encoder output in catalogue chunks,
+    every dlogits row sums to zero (so do the untouched-by-lookup columns of dE), sampled dE rows equal
+    dlogits^T . h_last, and one Adam step moves exactly the rows that received gradient.  Size-independent
+    properties only: the numpy oracle does not run at this size."""
+    from bsarec_amd import BSARecModel, _lib as Lb
+    V, B, Lq, d = 10_000_001, 256, 50, 64
+    a = ns(item_size=V, num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(3)
+    model = BSARecModel(a).cuda()
+    model.train()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    ids = torch.randint(1, V, (B, Lq), device="cuda", generator=g)
+    ids[:, :20][torch.rand(B, 20, device="cuda", generator=g) < 0.5] = 0
+    ids[:, :20] = torch.where(torch.cummin(ids[:, :20].flip(1), 1).values.flip(1) == 0, 0, ids[:, :20])   # left padding
+    ans = torch.randint(1, V, (B,), device="cuda", generator=g)
+    ans[:4] = torch.tensor([1, V - 1, V - 2, 5_000_000], device="cuda")         # catalogue edges
+    loss = model.calculate_loss(ids, ans)
+    loss.backward()
+    h = model.forward(ids)[:, -1, :].double()                                    # dropout off: same activations
+    E = model.item_embeddings.weight.detach()
+    m = torch.full((B,), -1e30, dtype=torch.float64, device="cuda"); ssum = torch.zeros_like(m)
+    for v0 in range(0, V, 1_000_000):
+        lg = h @ E[v0:v0 + 1_000_000].double().T
+        m2 = torch.maximum(m, lg.max(1).values)
+        ssum = ssum * torch.exp(m - m2) + torch.exp(lg - m2[:, None]).sum(1)
+        m = m2
+    lse = m + torch.log(ssum)
+    tgt = (h * E[ans].double()).sum(1)
+    ref = float((lse - tgt).mean().item())
+    assert abs(loss.item() - ref) <= 2e-6 * abs(ref), (loss.item(), ref)
+    plan = model._plan(B)
+    Vp = (V + 3) // 4 * 4
+    dlog = plan.view(Lb.BUF_DLOGITS, 0, (B, Vp))
+    assert float(dlog.double().sum(1).abs().max().item()) <= 1e-6
+    assert float(dlog[:, V:].abs().max().item()) == 0.0
+    dE = model.item_embeddings.weight.grad
+    probe = torch.tensor([0, 7, 123_457, 4_999_999, 9_999_999, V - 1], device="cuda")
+    probe = probe[~torch.isin(probe, ids.flatten())]                              # rows without a lookup gradient
+    want = dlog[:, probe].double().T @ h
+    assert float((dE[probe].double() - want).abs().max().item()) <= 1e-5 * float(want.abs().max().item())   # fp32 sum over 256 rows
+    # lookup rows: dE[row] - logits part = sum of the embedding-path gradient rows of that id (non-zero for used ids)
+    used = torch.unique(ids[ids > 0])[:64]
+    lookup = dE[used].double() - dlog[:, used].double().T @ h
+    assert float(lookup.abs().sum(1).min().item()) > 0.0
+    before = E[probe].clone()
+    model.configure_adam(lr=1e-3)
+    model.adam_step()
+    moved = (model.item_embeddings.weight.detach()[probe] - before).abs().max(1).values
+    assert bool((moved > 0).all())                       # every catalogue row has a (tiny) softmax gradient
+    assert torch.isfinite(model.item_embeddings.weight.detach()).all()
+
+
 def test_data_parallel_step_one_rank_rccl_equals_single_gpu_step():
     """The data-parallel step (forward / backward, summing all-reduce of the flat gradient arena over RCCL,
     Adam on sum / world) on a 1-rank "nccl" group gives the same parameters as the fused single-GPU step."""
