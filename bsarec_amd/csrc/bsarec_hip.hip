@@ -118,6 +118,7 @@ struct bsarec_plan {
     float *part_ln0, *part_pos, *trash;
     int pos_slices;
     ReduceJob* jobs; int jobs_per_layer;
+    int* blockmap; int red_blocks;           // flat block -> (job, chunk) table of the final gradient reduction
 };
 
 struct Carver {
@@ -178,6 +179,7 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     const long Td = T * d;
     Carver cv(base);
     p.jobs = cv.take<ReduceJob>((size_t)(N * 19 + 3));
+    p.blockmap = cv.take<int>((size_t)(N * (12 * cdiv(d * d, 64) + 16 * cdiv(4 * d, 64)) + cdiv(L * d, 64) + 2 * cdiv(d, 64) + 64));
     p.ids32 = cv.take<int>(T);
     for (int l = 0; l <= N; ++l) p.X[l] = cv.take<float>(Td);
     p.xhat0 = cv.take<float>(Td); p.rstd0 = cv.take<float>(T);
@@ -282,8 +284,14 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     add(p->part_ln0 + 1L * nb * d, p->G.ln_b, nb, d);
     add(p->part_pos, p->G.pos_emb, p->pos_slices, (long)cfg->seq_len * d);
     p->jobs_per_layer = 19;
+    std::vector<int> bmap;
+    for (size_t j = 0; j < jobs.size(); ++j)
+        for (int ch = 0; ch < cdiv(jobs[j].len, 64); ++ch) bmap.push_back((int)(j << 16) | ch);
+    p->red_blocks = (int)bmap.size();
     hipError_t e = hipMemcpyAsync(p->jobs, jobs.data(), jobs.size() * sizeof(ReduceJob), hipMemcpyHostToDevice,
                                   (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->blockmap, bmap.data(), bmap.size() * sizeof(int), hipMemcpyHostToDevice,
+                                            (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);   // jobs vector is host-temporary
     if (e != hipSuccess) { delete p; return (int)e; }
     // dry pass: sets every kernel's dynamic-LDS attribute for this shape without launching anything
@@ -434,6 +442,10 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
     if (top) { F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.vsplit; F.dh_stride = (long)c.batch * d; }
+    if (l == 0) {       // the embedding front-end's backward (Drop + LayerNorm) rides in the bottom block's epilogue
+        F.e_dz = p.dz; F.e_xhat = p.xhat0; F.e_rstd = p.rstd0; F.e_g = p.P.ln_w;
+        F.e_pg = p.part_ln0; F.e_pb = p.part_ln0 + nb * d; F.e_drop = make_drop(p, c.p_hidden, 0, tr);
+    }
     F.dT = p.dT; F.dU = p.dU; F.dO = p.dO; F.dq = p.dq; F.dk = p.dk; F.dv = p.dv;
     F.pg_ff = p.part_ln + 0 * nb * d; F.pb_ff = p.part_ln + 1 * nb * d; F.pg_a = p.part_ln + 2 * nb * d;
     F.pb_a = p.part_ln + 3 * nb * d; F.pg_f = p.part_ln + 4 * nb * d; F.pb_f = p.part_ln + 5 * nb * d;
@@ -469,8 +481,16 @@ extern "C" int bsarec_step_begin(bsarec_plan_t* p, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* stream, const GatherP& gp);
+
 extern "C" int bsarec_forward(bsarec_plan_t* p, const int64_t* ids, int train, void* stream) {
-    if (!p || !ids) return -10;
+    GatherP none;
+    memset(&none, 0, sizeof(none));
+    return forward_impl(p, ids, train, stream, none);
+}
+
+static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* stream, const GatherP& gp) {
+    if (!p || (!ids && !gp.table)) return -10;
     hipStream_t s = (hipStream_t)stream;
     const bsarec_config_t& c = p->cfg;
     const int T = p->T, d = c.hidden, L = c.seq_len, B = c.batch, h = c.heads, dh = p->dh, Lp = p->Lp;
@@ -480,7 +500,7 @@ extern "C" int bsarec_forward(bsarec_plan_t* p, const int64_t* ids, int train, v
 
     DISPATCH_LPR(d, {
         constexpr int RPB = ROW_THREADS / LPR;
-        LAUNCH(embed_fwd_kernel<LPR>, dim3(cdiv(T, RPB)), dim3(ROW_THREADS), 0, s, ids, p->P.item_emb,
+        LAUNCH(embed_fwd_kernel<LPR>, dim3(cdiv(T, RPB)), dim3(ROW_THREADS), 0, s, ids, gp, p->P.item_emb,
                            p->P.pos_emb, p->P.ln_w, p->P.ln_b, c.ln_eps, make_drop(*p, c.p_hidden, 0, tr), T, L, d,
                            c.item_size, p->X[0], p->xhat0, p->rstd0, p->ids32);
         HIPCHK(hipGetLastError());
@@ -595,7 +615,15 @@ extern "C" int bsarec_loss(bsarec_plan_t* p, const int64_t* answers, void* strea
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
+static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick);
+
 extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
+    TickP none;
+    memset(&none, 0, sizeof(none));
+    return backward_impl(p, stream, none);
+}
+
+static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
     if (!p) return -10;
     if (!p->G.item_emb) return -13;
     hipStream_t s = (hipStream_t)stream;
@@ -778,12 +806,15 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
     }
     // ---- embedding front-end backward
     {
+        hipStream_t se = s;
         LnBranch a; memset(&a, 0, sizeof(a));
         a.xhat = p->xhat0; a.rstd = p->rstd0; a.gamma = p->P.ln_w; a.in_scale = 1.f;
         a.drop = make_drop(*p, c.p_hidden, 0, tr); a.dT = nullptr;
         a.pgamma = p->part_ln0 + 0L * nb * d; a.pbeta = p->part_ln0 + 1L * nb * d;
-        DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, s, dY, a, a, p->dz, T, d, p->rows_pb));
-        HIPCHK(hipGetLastError());
+        if (!p->fused) {                  // fused path: done by the bottom block's backward kernel
+            DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, se, dY, a, a, p->dz, T, d, p->rows_pb));
+            HIPCHK(hipGetLastError());
+        }
         DISPATCH_LPR(d, {
             constexpr int CHUNK = SCATTER_FLOATS / (LPR * 4);
             constexpr size_t smem = SCATTER_FLOATS * 4 + 2 * CHUNK * 4;
@@ -794,12 +825,15 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
                 attr = true;
             }
             const int sb = cdiv(T, CHUNK);
-            LAUNCH(embed_bwd_kernel<LPR>, dim3(sb + L * p->pos_slices), dim3(ROW_THREADS), smem, s, p->dz, p->ids32, B, L, d,
+            LAUNCH(embed_bwd_kernel<LPR>, dim3(sb + L * p->pos_slices), dim3(ROW_THREADS), smem, se, p->dz, p->ids32, B, L, d,
                    p->G.item_emb, p->part_pos, sb);
             HIPCHK(hipGetLastError());
         });
         // ---- ONE deterministic second-stage reduction for every split-K slab and LayerNorm / beta partial
-        RET(launch_reduce(p->jobs, N * p->jobs_per_layer + 3, std::max(4L * d * d, (long)L * d), s));
+        // (no empty blocks: flat block map); its extra last block closes the optimisation step when asked to
+        LAUNCH(multi_reduce_flat_kernel, dim3(p->red_blocks + (tick.state ? 1 : 0)), dim3(ROW_THREADS), 0, s, p->jobs,
+               p->blockmap, p->red_blocks, tick);
+        HIPCHK(hipGetLastError());
     }
     return 0;
 }
@@ -807,11 +841,14 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // Adam / fused step
 // ---------------------------------------------------------------------------------------------
-static int launch_adam_tick(void* state, float lr, float b1, float b2, const float* loss_rows, int B, float* loss_out,
-                            void* cursor, int advance, int bump_step, hipStream_t s) {
-    LAUNCH(adam_tick_kernel, dim3(1), dim3(ROW_THREADS), 0, s, (uint64_t*)state, (double)lr, (double)b1, (double)b2, loss_rows, B,
-           loss_out, (long long*)cursor, advance, bump_step);
-    return (int)hipGetLastError();
+static TickP make_tick(void* state, int adam, float lr, float b1, float b2, const float* loss_rows, int B, float* loss_out,
+                       void* cursor, int advance, int bump_step) {
+    TickP t;
+    memset(&t, 0, sizeof(t));
+    t.state = (uint64_t*)state; t.adam = adam; t.lr = lr; t.b1 = b1; t.b2 = b2;
+    t.loss_rows = loss_rows; t.B = B; t.loss_out = loss_out;
+    t.cursor = (long long*)cursor; t.advance = advance; t.bump_step = bump_step;
+    return t;
 }
 
 static int adam_launch(float* params, const float* grads, float* m, float* v, long n, void* state, float b1, float b2,
@@ -828,7 +865,8 @@ extern "C" int bsarec_adam_step(float* params, const float* grads, float* m, flo
                                 float b1, float b2, float eps, float wd, float gscale, void* stream) {
     if (!params || !grads || !m || !v || !state || n <= 0 || (n & 3)) return -10;
     hipStream_t s = (hipStream_t)stream;
-    RET(launch_adam_tick(state, lr, b1, b2, nullptr, 0, nullptr, nullptr, 0, 0, s));
+    LAUNCH(adam_tick_kernel, dim3(1), dim3(ROW_THREADS), 0, s, make_tick(state, 1, lr, b1, b2, nullptr, 0, nullptr, nullptr, 0, 0));
+    HIPCHK(hipGetLastError());
     return adam_launch(params, grads, m, v, n, state, b1, b2, eps, wd, gscale, s);
 }
 
@@ -846,28 +884,26 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
                                          float* v, long n, float lr, float b1, float b2, float eps, float wd, void* stream) {
     if (!p || !params_flat || !grads_flat || !m || !v || n <= 0 || (n & 3)) return -10;
     hipStream_t s = (hipStream_t)stream;
-    RET(bsarec_gather_batch(table, answers_table, perm, n_samples, cursor, p->cfg.batch, p->cfg.seq_len, ids_buf,
-                            answers_buf, stream));
-    RET(bsarec_forward(p, ids_buf, 1, stream));
+    if (!table || !answers_table || !perm || !cursor || !ids_buf || !answers_buf) return -10;
+    GatherP gp{table, answers_table, perm, n_samples, (const long long*)cursor, ids_buf, answers_buf};
+    RET(forward_impl(p, ids_buf, 1, stream, gp));             // batch assembly rides in the embedding kernel
     RET(loss_impl(p, answers_buf, stream, false));
-    RET(bsarec_backward(p, stream));
-    // the Adam tick closes the step: mean loss, Adam t and bias corrections, next forward-step index, cursor += B
-    RET(launch_adam_tick(p->state, lr, b1, b2, p->loss_rows, p->cfg.batch, p->loss, cursor, p->cfg.batch, 1, s));
+    // the extra block of the final gradient reduction closes the step: mean loss, Adam t and bias corrections, next
+    // forward-step index, cursor += B
+    RET(backward_impl(p, stream, make_tick(p->state, 1, lr, b1, b2, p->loss_rows, p->cfg.batch, p->loss, cursor,
+                                           p->cfg.batch, 1)));
     return adam_launch(params_flat, grads_flat, m, v, n, p->state, b1, b2, eps, wd, 1.0f, s);
 }
 
 extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, const int64_t* answers_table,
                                         const int64_t* perm, long n_samples, void* cursor, int64_t* ids_buf,
                                         int64_t* answers_buf, void* stream) {
-    if (!p) return -10;
-    RET(bsarec_gather_batch(table, answers_table, perm, n_samples, cursor, p->cfg.batch, p->cfg.seq_len, ids_buf,
-                            answers_buf, stream));
-    RET(bsarec_forward(p, ids_buf, 1, stream));
+    if (!p || !table || !answers_table || !perm || !cursor || !ids_buf || !answers_buf) return -10;
+    GatherP gp{table, answers_table, perm, n_samples, (const long long*)cursor, ids_buf, answers_buf};
+    RET(forward_impl(p, ids_buf, 1, stream, gp));
     RET(bsarec_loss(p, answers_buf, stream));
-    RET(bsarec_backward(p, stream));
     // same convention as bsarec_train_step_indexed: the step index / cursor advance when the step is done
-    LAUNCH(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p->state, (long long*)cursor, p->cfg.batch);
-    return (int)hipGetLastError();
+    return backward_impl(p, stream, make_tick(p->state, 0, 0.f, 0.f, 0.f, nullptr, 0, nullptr, cursor, p->cfg.batch, 1));
 }
 
 extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int64_t* answers, float* params_flat,

@@ -687,6 +687,9 @@ struct FusedBwdP {
     DropP drop_f, drop_p, drop_o, drop_ff;
     float* trash;
     long long* stamps;
+    // bottom block only (e_dz != null): the embedding front-end's backward rides in the epilogue --
+    // y = Drop(LN(e)) (src/model/_abstract_model.py:14-24): de = LNbwd(dX * keep/(1-p)) -> e_dz instead of dX
+    float* e_dz; const float *e_xhat, *e_rstd, *e_g; float *e_pg, *e_pb; DropP e_drop;
 };
 
 template <int NKB, int LDW>
@@ -1196,19 +1199,42 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             }
             lds_barrier();
         }
-        f32x4 sb = {0, 0, 0, 0};
+        f32x4 sb = {0, 0, 0, 0}, sg0 = sb, sb0 = sb;
+        float* const e_dz = KARG(FusedBwdP, e_dz);
+        const float* const e_xhat = KARG(FusedBwdP, e_xhat);
+        const float* const e_rstd = KARG(FusedBwdP, e_rstd);
+        const DropP e_drop = KARG(FusedBwdP, e_drop);
+        f32x4 g0 = {0, 0, 0, 0};
+        if (e_dz) g0 = gld4(KARG(FusedBwdP, e_g) + lc);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = 32 * i + lr;
-            if (t < L) {
+            const bool ok = t < L;
+            const long e = (tok0 + t) * 64 + lc;
+            f32x4 dx = {0, 0, 0, 0}, xh = dx;
+            float rs = 0.f;
+            if (ok) {
                 const f32x4 xv = ld4(sXin + t * FS + lc), df = ld4(sdF + t * FS + lc);
                 const f32x4 lowx = lowpass_tab(spec, t, lc, L, cb, sTab);
                 const f32x4 lowg = lowpass_tab(spec + cb * 128, t, lc, L, cb, sTab);
-                gst4(R8_dX + (tok0 + t) * 64 + lc, ld4(sG + t * FS + lc) + b2 * df + lowg);
+                dx = ld4(sG + t * FS + lc) + b2 * df + lowg;
                 sb += df * (xv - lowx);
+                if (e_dz) { xh = gld4(e_xhat + e); rs = gld(e_rstd + tok0 + t); dx = dx * drop_mult4(e_drop, (uint64_t)e >> 2); }
+                else gst4(R8_dX + e, dx);
+            }
+            if (e_dz) {                                     // embedding LayerNorm backward on the finished row
+                const f32x4 gg = dx * g0;
+                const float m1 = group_sum<16>(gg.x + gg.y + gg.z + gg.w) * (1.0f / 64.0f);
+                const float m2 = group_sum<16>(gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w) * (1.0f / 64.0f);
+                if (ok) gst4(e_dz + e, rs * (gg - m1 - xh * m2));
+                sg0 += dx * xh; sb0 += dx;
             }
         }
         seq_partial_64(sb, sQ, R8_pbeta + (long)b * 64, 2.0f, R8_sqrt_beta);
+        if (e_dz) {
+            seq_partial_64(sg0, sQ, KARG(FusedBwdP, e_pg) + (long)b * 64);
+            seq_partial_64(sb0, sQ, KARG(FusedBwdP, e_pb) + (long)b * 64);
+        }
     }
     STAMP(8);
 }

@@ -11,9 +11,17 @@
 // =============================================================================================
 // K1 embedding front-end: X0 = Drop(LN(E[ids] + Pos[t]))      src/model/_abstract_model.py:14-24
 // =============================================================================================
+// Optional batch assembly folded into the embedding kernel (the device-resident sample table of bsarec_amd.data):
+// ids[b,:] = table[perm[cursor + b], :], answers[b] = ans_table[perm[cursor + b]]
+// (replaces RandomSampler + DataLoader collation, src/dataset.py:207-211).  table == nullptr: ids come from `ids`.
+struct GatherP {
+    const int64_t* table; const int64_t* ans_table; const int64_t* perm; long n;
+    const long long* cursor; int64_t* ids_out; int64_t* ans_out;
+};
+
 template <int LPR>
 __global__ void __launch_bounds__(ROW_THREADS)
-embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ E, const float* __restrict__ Pos,
+embed_fwd_kernel(const int64_t* __restrict__ ids, GatherP gp, const float* __restrict__ E, const float* __restrict__ Pos,
                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, DropP drop,
                  int T, int L, int d, int V, float* __restrict__ X0, float* __restrict__ xhat,
                  float* __restrict__ rstd, int* __restrict__ ids32) {
@@ -23,7 +31,18 @@ embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ E, c
     const bool ok = tok < T && lc < d;
     f32x4 v = {0, 0, 0, 0};
     if (ok) {
-        int id = (int)ids[tok];
+        int64_t id64;
+        if (gp.table) {
+            const int b = tok / L, t = tok - b * L;
+            long src = *gp.cursor + b;
+            src = src < gp.n ? gp.perm[src] : 0;
+            id64 = gp.table[src * L + t];
+            if (lc == 0) {
+                gp.ids_out[tok] = id64;
+                if (t == 0) gp.ans_out[b] = gp.ans_table[src];
+            }
+        } else id64 = ids[tok];
+        int id = (int)id64;
         id = id < 0 ? 0 : (id >= V ? V - 1 : id);     // defensive clamp: never read outside the table
         if (lc == 0) ids32[tok] = id;
         v = ld4(E + (long)id * d + lc) + ld4(Pos + (long)(tok % L) * d + lc);
@@ -483,13 +502,9 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
 // =============================================================================================
 struct ReduceJob { const float* src; float* dst; int nsplit; int len; long stride; float scale; int pad; };
 
-__global__ void __launch_bounds__(ROW_THREADS)
-multi_reduce_kernel(const ReduceJob* __restrict__ jobs) {
-    __shared__ float red[4][64];
-    const ReduceJob j = jobs[blockIdx.y];
+__device__ __forceinline__ void reduce_chunk(const ReduceJob& j, int chunk, float (*red)[64]) {
     const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;       // element within the block, split group
-    const int i = blockIdx.x * 64 + e;
-    if (blockIdx.x * 64 >= j.len) return;
+    const int i = chunk * 64 + e;
     float a[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) a[k] = 0.f;
@@ -510,9 +525,22 @@ multi_reduce_kernel(const ReduceJob* __restrict__ jobs) {
     if (sg == 0 && i < j.len) j.dst[i] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * j.scale;
 }
 
+// 2-D form: blockIdx.y = job, blockIdx.x = 64-element chunk (blocks past a job's length exit)
+__global__ void __launch_bounds__(ROW_THREADS)
+multi_reduce_kernel(const ReduceJob* __restrict__ jobs) {
+    __shared__ float red[4][64];
+    const ReduceJob j = jobs[blockIdx.y];
+    if (blockIdx.x * 64 >= j.len) return;
+    reduce_chunk(j, blockIdx.x, red);
+}
+
+// Flat form used by the training step: blockmap[b] = job << 16 | chunk for the nblocks useful blocks only (no empty
+// blocks); when tick.state != null one extra block closes the optimisation step next to the reduction
+// (multi_reduce_flat_kernel, below TickP).
 // =============================================================================================
 // device-resident step state (lets a captured hipGraph replay with fresh dropout masks / Adam t):
-//   u64 state[0] = seed, [1] = forward-step counter, [2] = Adam t; f32 view of [3] = {lr/bc1, sqrt(bc2)}
+//   u64 state[0] = seed, [1] = forward-step counter, [2] = Adam t; f32 view of [3] = {lr/bc1, sqrt(bc2)};
+//   u32 view of [4] = ticket of the Adam kernel; f64 view of [5], [6] = b1^t, b2^t
 // =============================================================================================
 __global__ void step_begin_kernel(uint64_t* state, long long* cursor, int advance) {
     state[1] += 1;
@@ -535,15 +563,21 @@ gather_batch_kernel(const int64_t* __restrict__ table, const int64_t* __restrict
     }
 }
 
-// One 256-thread block: advances Adam's t and publishes the bias corrections; in the fused single-GPU step it also
-// closes the step: mean loss of the batch, forward-step counter (next dropout masks) and batch cursor.
-__global__ void __launch_bounds__(ROW_THREADS)
-adam_tick_kernel(uint64_t* state, double lr, double b1, double b2, const float* __restrict__ loss_rows, int B,
-                 float* __restrict__ loss_out, long long* cursor, int advance, int bump_step) {
-    __shared__ float red[ROW_THREADS];
-    if (loss_rows) {
+// Closing an optimisation step on the device (one 256-thread block): mean loss of the batch, Adam's t and bias
+// corrections (b1^t, b2^t kept as running products: no pow()), next forward-step index (fresh dropout masks), batch
+// cursor.  Runs as the extra last block of the gradient reduction (fused step) or as its own launch (bsarec_adam_step).
+struct TickP {
+    uint64_t* state;
+    double lr, b1, b2; int adam;                           // adam != 0: advance t, publish {lr/bc1, sqrt(bc2)}
+    const float* loss_rows; int B; float* loss_out;        // mean loss of the batch (loss_out null: not requested)
+    long long* cursor; int advance;                        // batch cursor of the device-resident sample table
+    int bump_step;                                         // state[1] += 1
+};
+
+__device__ __forceinline__ void tick_body(const TickP& tk, float* red /* [ROW_THREADS] */) {
+    if (tk.loss_out) {
         float s = 0.f;
-        for (int i = threadIdx.x; i < B; i += ROW_THREADS) s += loss_rows[i];
+        for (int k = threadIdx.x; k < tk.B; k += ROW_THREADS) s += tk.loss_rows[k];
         red[threadIdx.x] = s;
         __syncthreads();
         for (int o = ROW_THREADS / 2; o > 0; o >>= 1) {
@@ -552,15 +586,34 @@ adam_tick_kernel(uint64_t* state, double lr, double b1, double b2, const float* 
         }
     }
     if (threadIdx.x == 0) {
-        if (loss_rows) loss_out[0] = red[0] / (float)B;
-        const uint64_t t = state[2] + 1;
-        state[2] = t;
-        float* f = reinterpret_cast<float*>(state + 3);
-        f[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
-        f[1] = (float)sqrt(1.0 - pow(b2, (double)t));
-        if (bump_step) state[1] += 1;
-        if (cursor) *cursor += advance;
+        uint64_t* state = tk.state;
+        if (tk.loss_out) tk.loss_out[0] = red[0] / (float)tk.B;
+        if (tk.adam) {
+            double* prod = reinterpret_cast<double*>(state + 5);
+            const uint64_t t = state[2];
+            const double p1 = (t == 0 ? 1.0 : prod[0]) * tk.b1, p2 = (t == 0 ? 1.0 : prod[1]) * tk.b2;
+            prod[0] = p1; prod[1] = p2;
+            state[2] = t + 1;
+            float* f = reinterpret_cast<float*>(state + 3);
+            f[0] = (float)(tk.lr / (1.0 - p1));
+            f[1] = (float)sqrt(1.0 - p2);
+        }
+        if (tk.bump_step) state[1] += 1;
+        if (tk.cursor) *tk.cursor += tk.advance;
     }
+}
+
+__global__ void __launch_bounds__(ROW_THREADS) adam_tick_kernel(TickP tk) {
+    __shared__ float red[ROW_THREADS];
+    tick_body(tk, red);
+}
+
+__global__ void __launch_bounds__(ROW_THREADS)
+multi_reduce_flat_kernel(const ReduceJob* __restrict__ jobs, const int* __restrict__ blockmap, int nblocks, TickP tk) {
+    __shared__ float red[ROW_THREADS];
+    if ((int)blockIdx.x >= nblocks) { tick_body(tk, red); return; }
+    const int bm = blockmap[blockIdx.x];
+    reduce_chunk(jobs[bm >> 16], bm & 0xFFFF, reinterpret_cast<float(*)[64]>(red));
 }
 
 // K9 fused Adam over the flat parameter arena (torch.optim.Adam semantics, src/trainers.py:27-28):

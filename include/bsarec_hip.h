@@ -68,7 +68,7 @@ enum {
     BSAREC_BUF_DSP = 3,        /* [B,L,d]   FrequencyLayer output of layer l (generic path only; stays on chip in the fused path) */
     BSAREC_BUF_HMIX = 4,       /* [B,L,d]   alpha*dsp + (1-alpha)*gsp of layer l */
     BSAREC_BUF_PROBS = 5,      /* [B,h,L,Lp] attention probabilities of layer l (before dropout) */
-    BSAREC_BUF_DLAYER_IN = 6,  /* [B,L,d]   gradient w.r.t. layer output l (ping-pong pair: only l = 0, 1 survive backward) */
+    BSAREC_BUF_DLAYER_IN = 6,  /* [B,L,d]   gradient w.r.t. layer output l (ping-pong pair: only l = 0, 1 survive backward; on the fused path l = 0 is never materialised: the bottom block emits the embedding gradient directly) */
     BSAREC_BUF_LOSS_ROWS = 7,  /* [B]       per-sequence cross-entropy */
     BSAREC_BUF_CTX = 8,        /* [B,L,d]   attention context of layer l */
     BSAREC_BUF_DLOGITS = 9     /* [B,Vp]    d loss / d logits = (softmax - onehot(answer)) / B, pad columns = 0 (after bsarec_loss) */
@@ -83,8 +83,9 @@ int bsarec_abi_version(void);
 size_t bsarec_workspace_bytes(const bsarec_config_t *cfg);
 
 /* Device step state: 8 x uint64.  [0] seed of the Philox dropout stream, [1] forward-step counter,
- * [2] Adam step t, [3] two packed floats written by bsarec_adam_step.  The caller zero-initialises
- * it and sets [0]; kernels read/advance it on the device so a captured graph replays correctly. */
+ * [2] Adam step t, [3] two packed floats written by bsarec_adam_step ({lr/bc1, sqrt(bc2)}), [4] ticket counter of
+ * the Adam kernel (uint32), [5], [6] beta1^t, beta2^t as doubles, [7] reserved.  The caller zero-initialises it and
+ * sets [0]; kernels read/advance it on the device so a captured graph replays correctly; t = 0 restarts Adam. */
 #define BSAREC_STATE_BYTES 64
 
 /* Build a launch plan.  `params`/`grads` hold device pointers (copied into the plan); `workspace`
@@ -136,8 +137,9 @@ int bsarec_train_step(bsarec_plan_t *plan, const int64_t *ids, const int64_t *an
 int bsarec_gather_batch(const int64_t *table, const int64_t *answers_table, const int64_t *perm, long n_samples,
                         const void *cursor, int B, int L, int64_t *ids_out, int64_t *answers_out, void *stream);
 
-/* bsarec_train_step fed from the resident table: gather the batch at *cursor, forward + loss + backward + Adam; the
- * Adam tick closes the step (mean loss, forward-step index += 1, *cursor += B).  A captured graph of this call
+/* bsarec_train_step fed from the resident table: the embedding kernel assembles the batch at *cursor (and fills
+ * ids_buf / answers_buf), forward + loss + backward + Adam; the Adam kernel's last block closes the step (mean loss,
+ * forward-step index += 1, *cursor += B).  A captured graph of this call
  * replays a whole epoch with no host work. */
 int bsarec_train_step_indexed(bsarec_plan_t *plan, const int64_t *table, const int64_t *answers_table,
                               const int64_t *perm, long n_samples, void *cursor, int64_t *ids_buf, int64_t *answers_buf,
