@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbsarec_hip.so")
+LIB_PATH = os.environ.get("BSAREC_LIB") or os.path.join(HERE, "libbsarec_hip.so")   # BSAREC_LIB: another build of the same ABI
 MAX_LAYERS = 16
 ABI_VERSION = 1
 

@@ -70,45 +70,58 @@ struct TileLoader {
         return x;
     }
 
-    // rows [r0, r0+R) limited by rlim; k range [k0, k0+BK) limited by klim
-    __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int r0, int rlim, int k0, int klim,
-                                         const XformP& X, int zb) {
+    int r0_, k0_, rlim_, klim_;     // tile origin / limits of the stage in flight (the transform needs them at store time)
+
+    // rows [r0, r0+R) limited by rlim; k range [k0, k0+BK) limited by klim.  Only ISSUES the loads: the element
+    // transform (GELU / dropout) is applied in store(), when the data is consumed -- applying it here would make
+    // the wave wait for the round trip at issue time and serialise the prefetch.
+    __device__ __forceinline__ void load(const float* __restrict__ base, long ld, int r0, int rlim, int k0, int klim) {
         const int tid = threadIdx.x;
+        r0_ = r0; k0_ = k0; rlim_ = rlim; klim_ = klim;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int idx = tid + p * GEMM_THREADS;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
             if (!KM) {
                 const int gr = r0 + (idx >> 3), gk = k0 + ((idx & 7) << 2);
-                const bool ok = gr < rlim && gk < klim;
-                if (ok) x = ld4(base + (long)gr * ld + gk);
-                x = xform(x, gr, gk, ok, X, zb);
+                if (gr < rlim && gk < klim) x = ld4(base + (long)gr * ld + gk);
             } else {
                 constexpr int RV = R / 4;
                 const int gk = k0 + idx / RV, gr = r0 + ((idx % RV) << 2);
-                bool ok = false;
                 if (gk < klim) {
                     const float* src = base + (long)gk * ld + gr;
-                    if (gr + 3 < rlim) { x = ld4(src); ok = true; }
+                    if (gr + 3 < rlim) x = ld4(src);
                     else {
-                        if (gr < rlim) { x.x = src[0]; ok = true; }
+                        if (gr < rlim) x.x = src[0];
                         if (gr + 1 < rlim) x.y = src[1];
                         if (gr + 2 < rlim) x.z = src[2];
                     }
                 }
-                x = xform(x, gk, gr, ok, X, zb);
             }
             v[p] = x;
         }
     }
 
-    __device__ __forceinline__ void store(float* s) const {
+    __device__ __forceinline__ void store(float* s, const XformP& X, int zb) const {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int idx = tid + p * GEMM_THREADS;
-            if (!KM) st4(s + (idx >> 3) * (GEMM_BK + 4) + ((idx & 7) << 2), v[p]);
-            else { constexpr int RV = R / 4; st4(s + (idx / RV) * R + ((idx % RV) << 2), v[p]); }
+            f32x4 x = v[p];
+            if (!KM) {
+                if (XF != XF_NONE) {
+                    const int gr = r0_ + (idx >> 3), gk = k0_ + ((idx & 7) << 2);
+                    x = xform(x, gr, gk, gr < rlim_ && gk < klim_, X, zb);
+                }
+                st4(s + (idx >> 3) * (GEMM_BK + 4) + ((idx & 7) << 2), x);
+            } else {
+                constexpr int RV = R / 4;
+                if (XF != XF_NONE) {
+                    const int gk = k0_ + idx / RV, gr = r0_ + ((idx % RV) << 2);
+                    x = xform(x, gk, gr, gk < klim_ && gr < rlim_, X, zb);
+                }
+                st4(s + (idx / RV) * R + ((idx % RV) << 2), x);
+            }
         }
     }
 };
@@ -183,8 +196,8 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
         const int seg = (P.nseg > 1) ? it / ktiles : prob;
         const int kt = (P.nseg > 1) ? it % ktiles : it;
         const int k0 = kbeg + kt * BK;
-        la.load(P.A[seg] + aoff, P.lda, ctx.m0, P.M, k0, A_KM ? kvend : kend, X, zb);
-        lb.load(P.B[seg] + boff, P.ldb, ctx.n0, P.Nb, k0, B_KM ? kvend : kend, X, zb);
+        la.load(P.A[seg] + aoff, P.lda, ctx.m0, P.M, k0, A_KM ? kvend : kend);
+        lb.load(P.B[seg] + boff, P.ldb, ctx.n0, P.Nb, k0, B_KM ? kvend : kend);
     };
     auto compute = [&](const float* __restrict__ as, const float* __restrict__ bs) {
 #pragma unroll
@@ -216,27 +229,29 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
+#ifndef EXP_NO_BGRAD
         if (BGRAD && A_KM && by == 0 && tid < BM) {
 #pragma unroll 8
             for (int k = 0; k < BK; ++k) bsum += as[k * LDAS + tid];
         }
+#endif
     };
 
     if (nit > 0) issue(0, la0, lb0);
     if (nit > 1) issue(1, la1, lb1);
-    if (nit > 0) { la0.store(As0); lb0.store(Bs0); }
+    if (nit > 0) { la0.store(As0, X, zb); lb0.store(Bs0, X, zb); }
     lds_barrier();       // LDS-only: the prefetched global loads stay in flight
     for (int it = 0; it < nit; it += 2) {
         // even step: LDS buffer 0 = tile it, stage 1 = tile it+1, stage 0 is free
         if (it + 2 < nit) issue(it + 2, la0, lb0);
         compute(As0, Bs0);
-        if (it + 1 < nit) { la1.store(As1); lb1.store(Bs1); }
+        if (it + 1 < nit) { la1.store(As1, X, zb); lb1.store(Bs1, X, zb); }
         lds_barrier();       // LDS-only: the prefetched global loads stay in flight
         if (it + 1 >= nit) break;
         // odd step: LDS buffer 1 = tile it+1, stage 0 = tile it+2, stage 1 is free
         if (it + 3 < nit) issue(it + 3, la1, lb1);
         compute(As1, Bs1);
-        if (it + 2 < nit) { la0.store(As0); lb0.store(Bs0); }
+        if (it + 2 < nit) { la0.store(As0, X, zb); lb0.store(Bs0, X, zb); }
         lds_barrier();       // LDS-only: the prefetched global loads stay in flight
     }
     if (BGRAD && A_KM && by == 0 && tid < BM && ctx.m0 + tid < P.M)
