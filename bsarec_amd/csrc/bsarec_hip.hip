@@ -3,6 +3,7 @@
 #include "epilogues.h"
 #include "kernels.h"
 #include "fused_layer.h"
+#include "dw_direct.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -21,7 +22,8 @@ static thread_local bool g_dry = false;
 #define LAUNCH(...) do { if (!g_dry) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 static long long* g_stamps = nullptr;   // diagnostic stamp buffer (bsarec_debug_stamps)
-static int g_use_fused = 1;      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
+static int g_use_fused = 1;
+static int g_use_direct_dw = 1;      // BSAREC_DW=tiled selects the LDS-tiled grouped kernel at the fused shape too      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long rup(long a, long b) { return (a + b - 1) / b * b; }
@@ -210,6 +212,9 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     p.pos_slices = cdiv(B, 64);
     p.part_pos = cv.take<float>((long)p.pos_slices * L * d);
     p.trash = cv.take<float>(1024);
+    // guard pad: the direct weight-gradient kernel prefetches up to 40 token rows past a slice without predicates
+    // (dw_direct.h); at the pruned top block those rows are L tokens apart
+    if (p.fused) cv.take<char>((size_t)48 * L * 4 * d * sizeof(float));
     *total = cv.off;
 }
 
@@ -250,6 +255,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     if (grads) p->G = *grads; else memset(&p->G, 0, sizeof(p->G));
     p->ws = (char*)workspace; p->ws_bytes = workspace_bytes;
     p->state = (uint64_t*)state; p->twiddle = twiddle; p->train = false;
+    if (const char* e = getenv("BSAREC_DW")) g_use_direct_dw = strcmp(e, "tiled") != 0;
     derive(*p);
     size_t total = 0;
     carve(*p, p->ws, &total);
@@ -794,10 +800,29 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                 tiles += cdiv(sp[i].M, 64) * G.tiles_n[i];
             }
             G.tile0[6] = tiles; G.nprob = 6;
+            if (p->fused && g_use_direct_dw) {
+                // hidden = 64: direct split-K products, one wave per (problem, 32x64 / 64x32 tile, slice) -- dw_direct.h
+                DwP D;
+                memset(&D, 0, sizeof(D));
+                int nu = 0;
+                for (int i = 0; i < 6; ++i) {
+                    const GemmP& g = G.P[i];
+                    DwProblem& q = D.P[i];
+                    q.A = g.A[0]; q.B = g.B[0]; q.lda = g.lda; q.ldb = g.ldb; q.M = g.M; q.N = g.N; q.K = g.K;
+                    q.kchunk = g.kchunk; q.slab = G.E[i].C[0]; q.bslab = G.bgrad[i]; q.gelu = G.b_gelu[i];
+                    if (q.gelu) { for (int n0 = 0; n0 < q.N; n0 += 32) D.U[nu++] = DwUnit{(short)i, 0, (short)n0, 1}; }
+                    else { for (int m0 = 0; m0 < q.M; m0 += 32) D.U[nu++] = DwUnit{(short)i, (short)m0, 0, 0}; }
+                }
+                D.units_per_split = nu; D.nsplit = ns;
+                ProfScope prof(BSAREC_K_DW1, s);
+                LAUNCH(dw_direct_kernel, dim3(cdiv(nu * ns, 4)), dim3(256), 0, s, D);
+                HIPCHK(hipGetLastError());
+            } else {
             constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES;
             ProfScope prof(BSAREC_K_DW1, s);
             LAUNCH(gemm_grouped_tn_kernel, dim3(tiles, ns), dim3(GEMM_THREADS), smem, s, G);
             HIPCHK(hipGetLastError());
+            }
         }
         // ---- FrequencyLayer backward: completes dX of this layer
         if (!p->fused)
