@@ -815,7 +815,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                 }
                 D.units_per_split = nu; D.nsplit = ns;
                 ProfScope prof(BSAREC_K_DW1, s);
-                LAUNCH(dw_direct_kernel, dim3(cdiv(nu * ns, 4)), dim3(256), 0, s, D);
+                LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * cdiv(nu, 4)), dim3(256), 0, s, D);
                 HIPCHK(hipGetLastError());
             } else {
             constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES;
