@@ -191,7 +191,8 @@ def main():
                       B * L * (24 * d * d + 8 * L * d + 16 * cb * d)),
                      (Lb.K_FUSED_FWD, "fused_layer_fwd_kernel (whole BSARecBlock forward per sequence)",
                       B * L * (24 * d * d + 4 * L * d + 8 * cb * d)),
-                     (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d)]
+                     (Lb.K_DW1, "dw_direct_kernel (6 weight + bias gradients of a block, direct split-K; un-pruned FLOP count, "
+                                "the top block's launch reduces 4 of its 6 products over the last positions only)", 24.0 * T * d * d)]
         else:
             cands = [(Lb.K_FFN1, "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)", 2.0 * T * d * 4 * d),
                      (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d)]
@@ -221,7 +222,7 @@ def main():
         def pmc_traffic(kernel_prefix):
             # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/): WRITE_SIZE + 2 * FETCH_SIZE KiB
             # (gfx950 tallies wide streaming reads at half their bytes, MI355X guide, HBM section)
-            path = os.path.join(ROOT, "profiles", "r01_c_pmc_C1.csv")
+            path = os.path.join(ROOT, "profiles", "r01_d_pmc_C1.csv")
             if not os.path.exists(path) or not fused or a.batch != 256:
                 return None
             vals = {}
