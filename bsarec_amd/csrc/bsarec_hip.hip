@@ -160,9 +160,9 @@ static void derive(bsarec_plan& p) {
     // LayerNorm gamma/beta partials: one row per 64-token block, or one per sequence on the fused path
     p.nblk = p.fused ? c.batch : cdiv(p.T, 64);
     p.rows_pb = p.fused ? c.seq_len : 64;
-    // split-K over tokens for the weight-gradient products: 32-aligned chunks; 80 slices at the fused shape (measured
-    // sweep 16..120 at C1: 0.330 0.314 0.301 0.292 0.291 0.288 0.295 ms/step), 40 elsewhere
-    int want_splits = p.fused ? 80 : 40;
+    // split-K over tokens for the weight-gradient products: ~40 slab slices, 32-aligned chunks (the direct kernel of
+    // the fused shape cuts every slice into 4 more quarters inside a workgroup)
+    int want_splits = 40;
     if (const char* e = getenv("BSAREC_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) want_splits = v; }   // tuning knob
     long ch = rup(cdiv(p.T, want_splits), GEMM_BK);
     if (ch < 64) ch = 64;
@@ -801,7 +801,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
             }
             G.tile0[6] = tiles; G.nprob = 6;
             if (p->fused && g_use_direct_dw) {
-                // hidden = 64: direct split-K products, one wave per (problem, 32x64 / 64x32 tile, slice) -- dw_direct.h
+                // hidden = 64: direct split-K products, one workgroup per (problem, 64x64 tile, slab slice) -- dw_direct.h
                 DwP D;
                 memset(&D, 0, sizeof(D));
                 int nu = 0;
@@ -810,12 +810,12 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                     DwProblem& q = D.P[i];
                     q.A = g.A[0]; q.B = g.B[0]; q.lda = g.lda; q.ldb = g.ldb; q.M = g.M; q.N = g.N; q.K = g.K;
                     q.kchunk = g.kchunk; q.slab = G.E[i].C[0]; q.bslab = G.bgrad[i]; q.gelu = G.b_gelu[i];
-                    if (q.gelu) { for (int n0 = 0; n0 < q.N; n0 += 32) D.U[nu++] = DwUnit{(short)i, 0, (short)n0, 1}; }
-                    else { for (int m0 = 0; m0 < q.M; m0 += 32) D.U[nu++] = DwUnit{(short)i, (short)m0, 0, 0}; }
+                    for (int m0 = 0; m0 < q.M; m0 += 64)
+                        for (int n0 = 0; n0 < q.N; n0 += 64) D.U[nu++] = DwUnit{(short)i, (short)m0, (short)n0, 0};
                 }
-                D.units_per_split = nu; D.nsplit = ns;
+                D.nunits = nu; D.nslab = ns;
                 ProfScope prof(BSAREC_K_DW1, s);
-                LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * cdiv(nu, 4)), dim3(256), 0, s, D);
+                LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * nu), dim3(256), 0, s, D);
                 HIPCHK(hipGetLastError());
             } else {
             constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES;

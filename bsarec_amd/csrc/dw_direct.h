@@ -3,148 +3,184 @@
 //   dW[o][i] = sum_t G[t][o] . Act[t][i]      (six products: query/key/value/dense, dense_1, dense_2;
 //   db[o]    = sum_t G[t][o]                   src/model/_modules.py:29-32,89-96 through autograd)
 //
-// Both operands are token-major, i.e. k-major for this product, which is exactly the MFMA operand shape: for
-// v_mfma_f32_32x32x2_f32 lane l supplies A[k = l>>5][m = l&31] and B[k = l>>5][n = l&31], so a wave reads its
-// fragments STRAIGHT from global memory -- per instruction two 128-byte row segments -- and needs neither LDS nor
-// barriers.  Every wave is an independent unit: one (problem, 32x64 or 64x32 output tile, split-K slice); it keeps
-// STAGES k-blocks of 8 token rows in flight in registers, accumulates in two 32x32 accumulator tiles and writes its
-// slab; the step's flat reduction sums the slabs (deterministic).  The tiled LDS kernel this replaces at the fused
-// shape spent ~1 us per 32-deep k-step on store -> barrier -> fragment-read latency with 16 MFMAs per wave in it.
+// Both operands are token-major, i.e. k-major for this product, which is the MFMA operand shape itself: for
+// v_mfma_f32_32x32x2_f32 lane l supplies A[k = l>>5][m(l&31)] and B[k = l>>5][n(l&31)], and the 32 m (n) values of a
+// tile may be ANY 32 columns.  A wave owns a 64 x 64 output tile as 2 x 2 interleaved 32 x 32 tiles -- tile (i, j)
+// holds rows m0 + 2a + i, columns n0 + 2b + j -- so that one 8-byte load per lane per token row feeds both m tiles
+// (resp. both n tiles): fragments come STRAIGHT from global memory, 512 contiguous bytes per wave instruction, with
+// neither LDS staging nor barriers in the k loop.  Per k-block of 8 token rows a wave issues 8 such loads for 16
+// MFMAs and keeps DW_STAGES k-blocks in flight in registers.
+//
+// Work decomposition: unit = (problem, 64 x 64 tile); the token axis is cut into `nslab` slab slices, each slice
+// again into 4 quarters taken by the 4 waves of a workgroup, which add their accumulators through LDS and write ONE
+// slab; the step's flat reduction sums the nslab slabs (deterministic, fixed order).  The LDS-tiled kernel this
+// replaces at the fused shape spent ~1 us per 32-deep k-step on store -> barrier -> fragment-read latency.
 #pragma once
 #include "fused_layer.h"
 
 #define DW_MAX_PROB 6
-#define DW_MAX_UNITS 32
-#define DW_STAGES 4
+#define DW_MAX_UNITS 16
+#define DW_STAGES 5
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gld2(const float* p) { return *reinterpret_cast<const AS_GLOBAL f32x2*>((const AS_GLOBAL float*)p); }
+__device__ __forceinline__ void gst2(float* p, f32x2 v) { *reinterpret_cast<AS_GLOBAL f32x2*>((AS_GLOBAL float*)p) = v; }
 
 struct DwProblem {
-    const float* A; const float* B;     // gradient rows [K][M] (lda), activation rows [K][N] (ldb)
+    const float* A; const float* B;     // gradient rows [K][M] (lda), activation rows [K][N] (ldb); M, N multiples of 64
     long lda, ldb;
-    int M, N, K, kchunk;                // K tokens in total, kchunk per slice (multiple of 8)
-    float* slab;                        // [nsplit][M][N]
-    float* bslab;                       // [nsplit][M]
+    int M, N, K, kchunk;                // K tokens in total, kchunk per slab slice (multiple of 32)
+    float* slab;                        // [nslab][M][N]
+    float* bslab;                       // [nslab][M]
     int gelu;                           // erf-GELU on the activation operand while loading (dW2 = dT2^T . gelu(u))
 };
 
-struct DwUnit { short prob, m0, n0, wide_m; };      // wide_m: 64(m) x 32(n) tile, else 32(m) x 64(n)
+struct DwUnit { short prob, m0, n0, pad; };
 
 struct DwP {
     DwProblem P[DW_MAX_PROB];
     DwUnit U[DW_MAX_UNITS];
-    int units_per_split, nsplit;
+    int nunits, nslab;
 };
 
-// one k-block (8 token rows) of operand registers: lane half h holds rows 4h .. 4h+3
-struct DwStage { float a[2][4]; float b[2][4]; };
+// one k-block (8 token rows) of operand registers: lane half h holds rows 4h .. 4h+3, two columns of each operand
+struct DwStage { f32x2 a[4]; f32x2 b[4]; };
 
 // Issue only: no predicate, no branch (a predicated load becomes a branch, after which the compiler can no longer
-// count the loads in flight and falls back to s_waitcnt vmcnt(0), i.e. no prefetch).  Reads may run up to
-// DW_STAGES + 1 k-blocks past the slice: inside the buffer that is the next slice's rows, past the buffer it is
-// the workspace's guard pad (bsarec_hip.hip, carve); such rows are zeroed when consumed.
-template <bool WIDE_M>
-__device__ __forceinline__ void dw_issue(DwStage& st, const float* __restrict__ pa, const float* __restrict__ pb, long lda,
-                                         long ldb) {
+// count the loads in flight and falls back to s_waitcnt vmcnt(0), i.e. no prefetch).  Buffer loads: the per-lane byte
+// offset (voff) is loop-invariant and the row offset is a scalar, so the k loop has no vector address arithmetic at
+// all.  Reads may run up to DW_STAGES + 1 k-blocks past the wave's rows: inside the buffer those are the next
+// slice's rows, past the buffer it is the workspace's guard pad (bsarec_hip.hip, carve); rows past the slice are
+// zeroed when consumed.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 bld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void dw_issue(DwStage& st, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob,
+                                         int soa, int sob, int rowa, int rowb) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        st.a[0][s] = gld(pa + s * lda);
-        if (WIDE_M) st.a[1][s] = gld(pa + s * lda + 32);
-        st.b[0][s] = gld(pb + s * ldb);
-        if (!WIDE_M) st.b[1][s] = gld(pb + s * ldb + 32);
+        st.a[s] = bld2(ra, voa, soa + s * rowa);
+        st.b[s] = bld2(rb, vob, sob + s * rowb);
     }
 }
 
-template <bool WIDE_M, bool GELU, bool MASK>
-__device__ __forceinline__ void dw_loop(const float* __restrict__ pa, const float* __restrict__ pb, long lda, long ldb, int nkb,
-                                        int crow, int kend, f32x16& acc0, f32x16& acc1, float& bs0, float& bs1) {
+template <bool GELU, bool MASK>
+__device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob, int soa, int sob,
+                                        int rowa, int rowb, int nkb, int crow, int kend, f32x16 (&acc)[2][2], f32x2& bs) {
     DwStage st[DW_STAGES];
 #pragma unroll
     for (int u = 0; u < DW_STAGES; ++u) {
-        dw_issue<WIDE_M>(st[u], pa, pb, lda, ldb);
-        pa += 8 * lda; pb += 8 * ldb;
+        dw_issue(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
+        soa += 8 * rowa; sob += 8 * rowb;
     }
-    for (int kb = 0; kb < nkb; kb += DW_STAGES) {       // nkb is a multiple of DW_STAGES (host: kchunk % 32 == 0)
+    for (int kb = 0; kb < nkb; kb += DW_STAGES) {       // nkb is a multiple of DW_STAGES (rows past kend count as zero)
 #pragma unroll
         for (int u = 0; u < DW_STAGES; ++u) {
             DwStage& cur = st[u];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
+                f32x2 a = cur.a[s], b = cur.b[s];
                 if (MASK) {
                     const bool ok = crow + s < kend;
-                    cur.a[0][s] = ok ? cur.a[0][s] : 0.f; cur.b[0][s] = ok ? cur.b[0][s] : 0.f;
-                    if (WIDE_M) cur.a[1][s] = ok ? cur.a[1][s] : 0.f; else cur.b[1][s] = ok ? cur.b[1][s] : 0.f;
+                    a.x = ok ? a.x : 0.f; a.y = ok ? a.y : 0.f; b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
                 }
-                if (GELU) {
-                    cur.b[0][s] = gelu_f(cur.b[0][s]);
-                    if (!WIDE_M) cur.b[1][s] = gelu_f(cur.b[1][s]);
-                }
-                bs0 += cur.a[0][s];
-                if (WIDE_M) bs1 += cur.a[1][s];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0][s], cur.b[0][s], acc0, 0, 0, 0);
-                if (WIDE_M) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1][s], cur.b[0][s], acc1, 0, 0, 0);
-                else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0][s], cur.b[1][s], acc1, 0, 0, 0);
+                if (GELU) { b.x = gelu_f(b.x); b.y = gelu_f(b.y); }
+                bs += a;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
             }
             crow += 8;
             // Refill the stage just consumed, DW_STAGES k-blocks ahead.  Pinned between scheduling barriers: left
             // free, the scheduler sinks these loads next to their next-iteration uses and waits vmcnt(0) before every
-            // MFMA pair, i.e. no prefetch at all.
+            // MFMA group, i.e. no prefetch at all.
             __builtin_amdgcn_sched_barrier(0);
-            dw_issue<WIDE_M>(st[u], pa, pb, lda, ldb);
-            pa += 8 * lda; pb += 8 * ldb;
+            dw_issue(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
+            soa += 8 * rowa; sob += 8 * rowb;
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-template <bool WIDE_M, bool GELU>
-__device__ __forceinline__ void dw_unit(const DwProblem& Q, int m0, int n0, int split) {
-    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-    const int kbeg = split * Q.kchunk, kend = min(Q.K, kbeg + Q.kchunk);
-    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * DW_STAGES - 1) / (8 * DW_STAGES)) * DW_STAGES : 0;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    float bs0 = 0.f, bs1 = 0.f;
-    if (nkb > 0) {                                       // wave-uniform; empty slices (pruned top block) only write zeros
-        const long lda = Q.lda, ldb = Q.ldb;
-        const float* pa = Q.A + (long)(kbeg + 4 * half) * lda + m0 + l31;
-        const float* pb = Q.B + (long)(kbeg + 4 * half) * ldb + n0 + l31;
-        const int crow = kbeg + 4 * half;
-        if (kbeg + 8 * nkb <= kend) dw_loop<WIDE_M, GELU, false>(pa, pb, lda, ldb, nkb, crow, kend, acc0, acc1, bs0, bs1);
-        else dw_loop<WIDE_M, GELU, true>(pa, pb, lda, ldb, nkb, crow, kend, acc0, acc1, bs0, bs1);
-    }
-    // slabs: accumulator register r of lane (l31, half) is C[m = rho(r) + 4 half][n = l31] of its 32x32 tile
-    float* C = Q.slab + (long)split * Q.M * Q.N;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mr = m0 + rho(r) + 4 * half;
-        gst(C + (long)mr * Q.N + n0 + l31, acc0[r]);
-        if (WIDE_M) gst(C + (long)(mr + 32) * Q.N + n0 + l31, acc1[r]);
-        else gst(C + (long)mr * Q.N + n0 + 32 + l31, acc1[r]);
-    }
-    if (n0 == 0) {        // bias gradient: column sums of the gradient operand (the two lane halves hold different rows)
-        bs0 = xor32_sum(bs0);
-        if (WIDE_M) bs1 = xor32_sum(bs1);
-        float* bo = Q.bslab + (long)split * Q.M + m0 + l31;
-        if (half == 0) { gst(bo, bs0); if (WIDE_M) gst(bo + 32, bs1); }
-    }
-}
-
-// The host builds the unit table so that the GELU problem (dense_2: M = 64, N = 256) is tiled 64(m) x 32(n) -- every
-// u element is loaded and activated by exactly one wave -- and everything else 32(m) x 64(n).
+// The host builds the unit table (64 x 64 tiles of the six problems: 4 + 4 + 4 = 12 units at hidden = 64).
 __global__ void __launch_bounds__(256)
 dw_direct_kernel(const DwP G) {
+    __shared__ __attribute__((aligned(16))) float red[3][66][64];      // accumulators (64) + bias sums (2) of waves 1..3
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All units of
-    // one split-K slice read the same token rows (X feeds the q/k/v tiles, hmix and dT2 eight tiles each), so a slice
-    // is kept on ONE XCD so that the re-reads hit that L2 (measured at C1: 22.9 us vs 23.7 us for the plain order;
-    // FETCH_SIZE stays near the 52 MB of unique operand bytes either way -- the kernel is latency-, not byte-bound).
+    // one slab slice read the same token rows (X feeds the q/k/v tiles, hmix and dT2 four tiles each), so a slice is
+    // kept on ONE XCD and the re-reads hit that L2.
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int wgs_per_split = (G.units_per_split + 3) >> 2;
-    const int split = xcd + 8 * (j / wgs_per_split);
-    const int unit_in_split = (j % wgs_per_split) * 4 + wv;
-    if (split >= G.nsplit || unit_in_split >= G.units_per_split) return;
-    const DwUnit u = G.U[unit_in_split];
+    const int slab = xcd + 8 * (j / G.nunits);
+    if (slab >= G.nslab) return;
+    const DwUnit u = G.U[j % G.nunits];
     const DwProblem& Q = G.P[u.prob];
-    if (u.wide_m) dw_unit<true, true>(Q, u.m0, u.n0, split);
-    else dw_unit<false, false>(Q, u.m0, u.n0, split);
+    const int m0 = u.m0, n0 = u.n0;
+    // this wave's quarter of the slab slice
+    const int sub = Q.kchunk >> 2;                                       // multiple of 8
+    const int kbeg = slab * Q.kchunk + wv * sub, kend = min(Q.K, kbeg + sub);
+    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * DW_STAGES - 1) / (8 * DW_STAGES)) * DW_STAGES : 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+    f32x2 bs = {0.f, 0.f};
+    if (nkb > 0) {                                       // wave-uniform; empty quarters (pruned top block) add zeros
+        // raw buffer descriptors over the operands (2 GB window: offsets below stay far inside 32 bits)
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Q.A, 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Q.B, 0, 0x7FFFFFFF, 0x00020000);
+        const int rowa = (int)Q.lda * 4, rowb = (int)Q.ldb * 4;                 // bytes per token row
+        const int voa = 4 * half * rowa + (m0 + 2 * l31) * 4, vob = 4 * half * rowb + (n0 + 2 * l31) * 4;
+        const int soa = kbeg * rowa, sob = kbeg * rowb;
+        const int crow = kbeg + 4 * half;
+        const bool full = kbeg + 8 * nkb <= kend;
+        if (Q.gelu) {
+            if (full) dw_loop<true, false>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs);
+            else dw_loop<true, true>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs);
+        } else {
+            if (full) dw_loop<false, false>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs);
+            else dw_loop<false, true>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs);
+        }
+    }
+    // bias gradient: column sums of the gradient operand; the two lane halves hold different token rows
+    bs.x = xor32_sum(bs.x); bs.y = xor32_sum(bs.y);
+    // the four quarters meet in LDS: waves 1..3 park their registers, wave 0 adds them in a fixed order
+    if (wv > 0) {
+        float (*mine)[64] = red[wv - 1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(i * 2 + jn) * 16 + r][lane] = acc[i][jn][r];
+        mine[64][lane] = bs.x; mine[65][lane] = bs.y;
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll 1
+    for (int w = 0; w < 3; ++w) {              // not unrolled: one wave's 66 values live at a time
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jn][r] += red[w][(i * 2 + jn) * 16 + r][lane];
+        bs.x += red[w][64][lane]; bs.y += red[w][65][lane];
+    }
+    // slab: register r of lane (l31, half) of tile (i, jn) is C[m0 + 2 (rho(r) + 4 half) + i][n0 + 2 l31 + jn]
+    float* C = Q.slab + (long)slab * Q.M * Q.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 2 * (rho(r) + 4 * half) + i;
+            gst2(C + (long)m * Q.N + n0 + 2 * l31, f32x2{acc[i][0][r], acc[i][1][r]});
+        }
+    if (n0 == 0 && half == 0) gst2(Q.bslab + (long)slab * Q.M + m0 + 2 * l31, bs);
 }
