@@ -55,6 +55,7 @@ EXPORTS = {
     "bsarec_buffer_offset": (C.c_long, [C.c_void_p, C.c_int, C.c_int]),
     "bsarec_step_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "bsarec_forward_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bsarec_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_logits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -73,6 +74,7 @@ EXPORTS = {
     "bsarec_freq_layer_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_int] +
                               [C.c_void_p] * 6),
     "bsarec_profile_select": (C.c_int, [C.c_int]),
+    "bsarec_set_prune_top": (C.c_int, [C.c_int]),
     "bsarec_set_fused": (C.c_int, [C.c_int]),
     "bsarec_debug_stamps": (C.c_int, [C.c_void_p]),
     "bsarec_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bsarec_hip.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("bsarec_hip.hip", "common.h", "gemm.h", "epilogues.h", "kernels.h", "fused_layer.h", "dw_direct.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("bsarec_hip.hip", "common.h", "gemm.h", "epilogues.h", "kernels.h", "fused_layer.h", "dw_direct.h", "fused_top.h")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "bsarec_hip.h"))
 OUT = os.path.join(HERE, "libbsarec_hip.so")
 

@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include "fused_layer.h"
 #include "dw_direct.h"
+#include "fused_top.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -23,6 +24,7 @@ static thread_local bool g_dry = false;
 
 static long long* g_stamps = nullptr;   // diagnostic stamp buffer (bsarec_debug_stamps)
 static int g_use_fused = 1;
+static int g_prune_top = 1;          // BSAREC_PRUNE_TOP=0: the loss path runs the full top block too
 static int g_use_direct_dw = 1;      // BSAREC_DW=tiled selects the LDS-tiled grouped kernel at the fused shape too      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -120,6 +122,10 @@ struct bsarec_plan {
     float *part_ln0, *part_pos, *trash;
     int pos_slices;
     ReduceJob* jobs; int jobs_per_layer;
+    ReduceJob* jobs_pruned;                    // same table with the top layer's key / value bias jobs fed from partials
+    bool prune_ok;                             // the loss path may run the pruned top block (fused shape, >= 2 layers)
+    bool pruned;                               // mode of the last forward
+    float *part_kvb, *slab_dummy;              // [2][B][d] key / value bias partials of the pruned top block; [nsplit][4d] sink
     int* blockmap; int red_blocks;           // flat block -> (job, chunk) table of the final gradient reduction
 };
 
@@ -182,6 +188,7 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     const long Td = T * d;
     Carver cv(base);
     p.jobs = cv.take<ReduceJob>((size_t)(N * 19 + 3));
+    p.jobs_pruned = cv.take<ReduceJob>((size_t)(N * 19 + 3));
     p.blockmap = cv.take<int>((size_t)(N * (12 * cdiv(d * d, 64) + 16 * cdiv(4 * d, 64)) + cdiv(L * d, 64) + 2 * cdiv(d, 64) + 64));
     p.ids32 = cv.take<int>(T);
     for (int l = 0; l <= N; ++l) p.X[l] = cv.take<float>(Td);
@@ -212,6 +219,8 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     p.pos_slices = cdiv(B, 64);
     p.part_pos = cv.take<float>((long)p.pos_slices * L * d);
     p.trash = cv.take<float>(1024);
+    p.part_kvb = cv.take<float>(2 * B * d);
+    p.slab_dummy = cv.take<float>((long)p.nsplit * 4 * d);
     // guard pad: the direct weight-gradient kernel prefetches up to 40 token rows past a slice without predicates
     // (dw_direct.h); at the pruned top block those rows are L tokens apart
     if (p.fused) cv.take<char>((size_t)48 * L * 4 * d * sizeof(float));
@@ -256,6 +265,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     p->ws = (char*)workspace; p->ws_bytes = workspace_bytes;
     p->state = (uint64_t*)state; p->twiddle = twiddle; p->train = false;
     if (const char* e = getenv("BSAREC_DW")) g_use_direct_dw = strcmp(e, "tiled") != 0;
+    if (const char* e = getenv("BSAREC_PRUNE_TOP")) { if (atoi(e) == 0) g_prune_top = 0; }
     derive(*p);
     size_t total = 0;
     carve(*p, p->ws, &total);
@@ -291,6 +301,14 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     add(p->part_ln0 + 1L * nb * d, p->G.ln_b, nb, d);
     add(p->part_pos, p->G.pos_emb, p->pos_slices, (long)cfg->seq_len * d);
     p->jobs_per_layer = 19;
+    p->prune_ok = p->fused && cfg->layers >= 2 && g_prune_top;
+    p->pruned = false;
+    std::vector<ReduceJob> jobs_pr = jobs;          // key_b is job 6, value_b job 8 of a layer's 19 (state_dict order)
+    {
+        const size_t base = (size_t)(cfg->layers - 1) * 19;
+        ReduceJob& jk = jobs_pr[base + 6]; jk.src = p->part_kvb; jk.nsplit = cfg->batch; jk.stride = d;
+        ReduceJob& jv = jobs_pr[base + 8]; jv.src = p->part_kvb + (long)cfg->batch * d; jv.nsplit = cfg->batch; jv.stride = d;
+    }
     std::vector<int> bmap;
     for (size_t j = 0; j < jobs.size(); ++j)
         for (int ch = 0; ch < cdiv(jobs[j].len, 64); ++ch) bmap.push_back((int)(j << 16) | ch);
@@ -299,14 +317,21 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
                                   (hipStream_t)stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->blockmap, bmap.data(), bmap.size() * sizeof(int), hipMemcpyHostToDevice,
                                             (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->jobs_pruned, jobs_pr.data(), jobs_pr.size() * sizeof(ReduceJob),
+                                            hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);   // jobs vector is host-temporary
     if (e != hipSuccess) { delete p; return (int)e; }
     // dry pass: sets every kernel's dynamic-LDS attribute for this shape without launching anything
     g_dry = true;
-    int rc = bsarec_forward(p, reinterpret_cast<const int64_t*>(p->ws), 1, stream);
-    if (rc == 0) rc = bsarec_loss(p, reinterpret_cast<const int64_t*>(p->ws), stream);
-    if (rc == 0 && p->G.item_emb) rc = bsarec_backward(p, stream);
+    int rc = 0;
+    for (int last = 0; last < 2 && rc == 0; ++last) {
+        rc = last ? bsarec_forward_last(p, reinterpret_cast<const int64_t*>(p->ws), 1, stream)
+                  : bsarec_forward(p, reinterpret_cast<const int64_t*>(p->ws), 1, stream);
+        if (rc == 0) rc = bsarec_loss(p, reinterpret_cast<const int64_t*>(p->ws), stream);
+        if (rc == 0 && p->G.item_emb) rc = bsarec_backward(p, stream);
+    }
     g_dry = false;
+    p->pruned = false;
     p->train = false;
     if (rc != 0) { delete p; return rc; }
     *out = p;
@@ -475,9 +500,74 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     return (int)hipGetLastError();
 }
 
+static int launch_top_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
+    const bsarec_config_t& c = p.cfg;
+    const bsarec_layer_t& w = p.P.layer[l];
+    LayerBufs& b = p.lb[l];
+    TopFwdP F;
+    memset(&F, 0, sizeof(F));
+    F.X = p.X[l]; F.Xout = p.X[l + 1];
+    F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.f_b = w.filter_ln_b;
+    F.wq = w.query_w; F.bq = w.query_b; F.wk = w.key_w; F.bk = w.key_b; F.wv = w.value_w; F.bv = w.value_b;
+    F.wo = w.dense_w; F.bo = w.dense_b; F.a_g = w.attn_ln_w; F.a_b = w.attn_ln_b;
+    F.w1 = w.ffn1_w; F.b1 = w.ffn1_b; F.w2 = w.ffn2_w; F.b2 = w.ffn2_b; F.ff_g = w.ffn_ln_w; F.ff_b = w.ffn_ln_b;
+    F.tw = p.twiddle; F.ids32 = p.ids32;
+    F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs; F.ctx = b.ctx;
+    F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.hmix = b.hmix; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
+    F.low = b.dsp;
+    F.L = c.seq_len; F.Lp = p.Lp; F.cb = c.cutoff_bins; F.heads = c.heads;
+    F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
+    F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
+    F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    const size_t smem = top_fwd_smem_bytes();
+#define TOP_FWD_CASE(DHV) { \
+        static bool attr = false; \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(top_fwd_kernel<DHV>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
+        LAUNCH(top_fwd_kernel<DHV>, dim3(c.batch), dim3(256), smem, s, F); }
+    if (p.dh == 16) TOP_FWD_CASE(16) else if (p.dh == 32) TOP_FWD_CASE(32) else TOP_FWD_CASE(64)
+#undef TOP_FWD_CASE
+    return (int)hipGetLastError();
+}
+
+static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStream_t s) {
+    const bsarec_config_t& c = p.cfg;
+    const bsarec_layer_t& w = p.P.layer[l];
+    LayerBufs& b = p.lb[l];
+    const long nb = p.nblk, d = c.hidden;
+    TopBwdP F;
+    memset(&F, 0, sizeof(F));
+    F.dX = dXout; F.X = p.X[l];
+    F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.wq = w.query_w; F.wk = w.key_w; F.wv = w.value_w; F.wo = w.dense_w;
+    F.a_g = w.attn_ln_w; F.w1 = w.ffn1_w; F.w2 = w.ffn2_w; F.ff_g = w.ffn_ln_w; F.tw = p.twiddle;
+    F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
+    F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff; F.low = b.dsp;
+    F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.vsplit; F.dh_stride = (long)c.batch * d;
+    F.dT = p.dT; F.dU = p.dU; F.dO = p.dO; F.dq = p.dq;
+    F.ak = p.dk; F.rk = p.dC; F.av = p.dv; F.rv = p.dF;
+    F.pbk = p.part_kvb; F.pbv = p.part_kvb + (long)c.batch * d;
+    F.pg_ff = p.part_ln + 0 * nb * d; F.pb_ff = p.part_ln + 1 * nb * d; F.pg_a = p.part_ln + 2 * nb * d;
+    F.pb_a = p.part_ln + 3 * nb * d; F.pg_f = p.part_ln + 4 * nb * d; F.pb_f = p.part_ln + 5 * nb * d;
+    F.pbeta = p.part_beta;
+    F.L = c.seq_len; F.Lp = p.Lp; F.cb = c.cutoff_bins; F.heads = c.heads;
+    F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha);
+    F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
+    F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    const size_t smem = top_bwd_smem_bytes();
+#define TOP_BWD_CASE(DHV) { \
+        static bool attr = false; \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(top_bwd_kernel<DHV>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
+        LAUNCH(top_bwd_kernel<DHV>, dim3(c.batch), dim3(256), smem, s, F); }
+    if (p.dh == 16) TOP_BWD_CASE(16) else if (p.dh == 32) TOP_BWD_CASE(32) else TOP_BWD_CASE(64)
+#undef TOP_BWD_CASE
+    return (int)hipGetLastError();
+}
+
 extern "C" int bsarec_debug_stamps(void* dev_buf) { g_stamps = (long long*)dev_buf; return 0; }
 
 extern "C" int bsarec_set_fused(int enable) { g_use_fused = enable ? 1 : 0; return 0; }
+extern "C" int bsarec_set_prune_top(int enable) { g_prune_top = enable ? 1 : 0; return 0; }
 
 extern "C" int bsarec_step_begin(bsarec_plan_t* p, void* stream) {
     if (!p) return -10;
@@ -488,21 +578,28 @@ extern "C" int bsarec_step_begin(bsarec_plan_t* p, void* stream) {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* stream, const GatherP& gp);
+static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* stream, const GatherP& gp, bool last_only);
 
 extern "C" int bsarec_forward(bsarec_plan_t* p, const int64_t* ids, int train, void* stream) {
     GatherP none;
     memset(&none, 0, sizeof(none));
-    return forward_impl(p, ids, train, stream, none);
+    return forward_impl(p, ids, train, stream, none, false);
 }
 
-static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* stream, const GatherP& gp) {
+extern "C" int bsarec_forward_last(bsarec_plan_t* p, const int64_t* ids, int train, void* stream) {
+    GatherP none;
+    memset(&none, 0, sizeof(none));
+    return forward_impl(p, ids, train, stream, none, true);
+}
+
+static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* stream, const GatherP& gp, bool last_only) {
     if (!p || (!ids && !gp.table)) return -10;
     hipStream_t s = (hipStream_t)stream;
     const bsarec_config_t& c = p->cfg;
     const int T = p->T, d = c.hidden, L = c.seq_len, B = c.batch, h = c.heads, dh = p->dh, Lp = p->Lp;
     const bool tr = train != 0;
     p->train = tr;
+    p->pruned = last_only && p->prune_ok;
     const XformP nox = no_xform();
 
     DISPATCH_LPR(d, {
@@ -518,7 +615,8 @@ static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* s
         LayerBufs& b = p->lb[l];
         const float* X = p->X[l];
         if (fused_ok(*p)) {
-            RET(launch_fused_fwd(*p, l, tr, s));
+            if (p->pruned && l == c.layers - 1) RET(launch_top_fwd(*p, l, tr, s));
+            else RET(launch_fused_fwd(*p, l, tr, s));
             continue;
         }
         // K2 FrequencyLayer
@@ -680,7 +778,10 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
         const float* X = p->X[l];
         float* dXout = (dY == p->dXa) ? p->dXb : p->dXa;
         p->slab_w = p->slab_wL[l]; p->slab_b = p->slab_bL[l]; p->part_ln = p->part_lnL[l]; p->part_beta = p->part_betaL[l];
-        if (p->fused) {
+        const bool top_pruned = p->fused && p->pruned && l == N - 1;
+        if (top_pruned) {
+            RET(launch_top_bwd(*p, l, tr, dXout, s));
+        } else if (p->fused) {
             RET(launch_fused_bwd(*p, l, tr, dY, dXout, s, l == N - 1));
         } else {
         // ---- FeedForward backward
@@ -790,10 +891,18 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                     g.lda *= L; g.ldb *= L;
                     g.kchunk = (int)rup(cdiv(B, ns), GEMM_BK);           // slices beyond ceil(B / kchunk) write zero slabs
                 }
+                // pruned top block: dK, dV are rank-1 per (sequence, head) -> dWk = AK^T RK, dWv = AV^T RV over B*h rows
+                // (fused_top.h); their bias gradients come from per-sequence partials, the slab output is discarded
+                const bool compact = top_pruned && (i == 1 || i == 2);
+                if (compact) {
+                    g = gemm_defaults(d, d, B * h);
+                    g.A[0] = i == 1 ? p->dk : p->dv; g.B[0] = i == 1 ? p->dC : p->dF; g.lda = d; g.ldb = d;
+                    g.nsplit = ns; g.kchunk = (int)rup(cdiv(B * h, ns), GEMM_BK);
+                }
                 G.P[i] = g;
                 G.E[i] = epi_linear<false, false, false>(slab_w_ptr(*p, sp[i].woff), sp[i].N);
                 G.E[i].c_split = (long)sp[i].M * sp[i].N;
-                G.bgrad[i] = slab_b_ptr(*p, sp[i].boff);
+                G.bgrad[i] = compact ? p->slab_dummy : slab_b_ptr(*p, sp[i].boff);
                 G.tile0[i] = tiles;
                 G.tiles_n[i] = cdiv(sp[i].N, 64);
                 G.b_gelu[i] = sp[i].gelu;
@@ -857,8 +966,8 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
         });
         // ---- ONE deterministic second-stage reduction for every split-K slab and LayerNorm / beta partial
         // (no empty blocks: flat block map); its extra last block closes the optimisation step when asked to
-        LAUNCH(multi_reduce_flat_kernel, dim3(p->red_blocks + (tick.state ? 1 : 0)), dim3(ROW_THREADS), 0, s, p->jobs,
-               p->blockmap, p->red_blocks, tick);
+        LAUNCH(multi_reduce_flat_kernel, dim3(p->red_blocks + (tick.state ? 1 : 0)), dim3(ROW_THREADS), 0, s,
+               p->pruned ? p->jobs_pruned : p->jobs, p->blockmap, p->red_blocks, tick);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -912,7 +1021,7 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
     hipStream_t s = (hipStream_t)stream;
     if (!table || !answers_table || !perm || !cursor || !ids_buf || !answers_buf) return -10;
     GatherP gp{table, answers_table, perm, n_samples, (const long long*)cursor, ids_buf, answers_buf};
-    RET(forward_impl(p, ids_buf, 1, stream, gp));             // batch assembly rides in the embedding kernel
+    RET(forward_impl(p, ids_buf, 1, stream, gp, true));       // batch assembly rides in the embedding kernel
     RET(loss_impl(p, answers_buf, stream, false));
     // the extra block of the final gradient reduction closes the step: mean loss, Adam t and bias corrections, next
     // forward-step index, cursor += B
@@ -926,7 +1035,7 @@ extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, 
                                         int64_t* answers_buf, void* stream) {
     if (!p || !table || !answers_table || !perm || !cursor || !ids_buf || !answers_buf) return -10;
     GatherP gp{table, answers_table, perm, n_samples, (const long long*)cursor, ids_buf, answers_buf};
-    RET(forward_impl(p, ids_buf, 1, stream, gp));
+    RET(forward_impl(p, ids_buf, 1, stream, gp, true));
     RET(bsarec_loss(p, answers_buf, stream));
     // same convention as bsarec_train_step_indexed: the step index / cursor advance when the step is done
     return backward_impl(p, stream, make_tick(p->state, 0, 0.f, 0.f, 0.f, nullptr, 0, nullptr, cursor, p->cfg.batch, 1));
@@ -936,7 +1045,7 @@ extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int
                                  const float* grads_flat, float* m, float* v, long n, float lr, float b1, float b2,
                                  float eps, float wd, void* stream) {
     RET(bsarec_step_begin(p, stream));
-    RET(bsarec_forward(p, ids, 1, stream));
+    RET(bsarec_forward_last(p, ids, 1, stream));
     RET(bsarec_loss(p, answers, stream));
     RET(bsarec_backward(p, stream));
     return bsarec_adam_step(params_flat, grads_flat, m, v, n, p->state, lr, b1, b2, eps, wd, 1.0f, stream);

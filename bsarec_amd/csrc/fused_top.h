@@ -1,0 +1,440 @@
+// The TOP BSARecBlock of the training step at the fused shape (hidden = 64, L <= 64), restricted to what the loss
+// can see.  calculate_loss reads only position L-1 of the last layer (src/model/bsarec.py:32), so of the top block
+// only that row has to exist -- but it still attends to every position: K and V of all rows are needed, everything
+// else (frequency layer, query, softmax row, dense, both LayerNorms, feed-forward) is a single row per sequence.
+// The backward has the mirror structure: the upstream gradient is one row, so dK, dV are rank-1 per head
+// (dK_j = ds_j q_last, dV_j = Drop(p)_j dC_last) and the whole input gradient is a handful of vector products:
+//   dX_j = sum_h ds_hj (q_h Wk_h) + sum_h Drop(p)_hj (dC_h Wv_h) + [j = L-1] (dq Wq + dzA + dzF + beta^2 dF)
+//          + P[j][L-1] ((1 - beta^2) dF)                         (P = the low-pass projector of the FrequencyLayer)
+// Results are those of the full block kernels (same formulas, same dropout stream, same buffers -- only the rows
+// the loss depends on are produced); the exact zero structure is used, nothing is approximated.  SURVEY C.6 / §8d:
+// the algorithmic FLOP counts reported by bench.py stay the un-pruned ones.
+// One workgroup of 256 threads per sequence; matrix-vector products by VALU with the weight rows streamed from L2.
+#pragma once
+#include "fused_layer.h"
+
+struct TopFwdP {
+    const float* X; float* Xout;
+    const float *sqrt_beta, *f_g, *f_b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *a_g, *a_b, *w1, *b1, *w2, *b2, *ff_g, *ff_b;
+    const float* tw; const int* ids32;
+    float *xhat_f, *rstd_f, *q, *k, *v, *probs, *ctx, *xhat_a, *rstd_a, *hmix, *u, *xhat_ff, *rstd_ff;
+    float* low;                    // [B, L, 64] buffer whose last rows receive the low-pass component (for d sqrt_beta)
+    int L, Lp, cb, heads;
+    float alpha, oma, eps;
+    DropP drop_f, drop_p, drop_o, drop_ff;
+};
+
+__device__ __forceinline__ float drop_mult1(const DropP& d, uint64_t e) {
+    const f32x4 m = drop_mult4(d, e >> 2);
+    const int j = (int)(e & 3);
+    return j == 0 ? m.x : j == 1 ? m.y : j == 2 ? m.z : m.w;
+}
+
+// y[n] = sum_k W[n][k] x[k]  (nn.Linear forward, W row-major [*][ldw]); KS adjacent lanes share one output
+template <int K, int KS>
+__device__ __forceinline__ float gemv_rows(const float* __restrict__ W, int ldw, const float* __restrict__ sx, int n, int slice) {
+    constexpr int KC = K / KS;
+    const float* w = W + (long)n * ldw + slice * KC;
+    const float* x = sx + slice * KC;
+    f32x4 wv[KC / 4];
+#pragma unroll
+    for (int i = 0; i < KC / 4; ++i) wv[i] = gld4(w + 4 * i);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < KC / 4; ++i) {
+        const f32x4 xv = ld4(x + 4 * i);
+        acc += wv[i].x * xv.x + wv[i].y * xv.y + wv[i].z * xv.z + wv[i].w * xv.w;
+    }
+    if (KS >= 2) acc += dpp_mov<0xB1>(acc);
+    if (KS >= 4) acc += dpp_mov<0x4E>(acc);
+    if (KS >= 8) acc += dpp_mov<0x141>(acc);
+    if (KS >= 16) acc += dpp_mov<0x140>(acc);
+    return acc;
+}
+
+// y[i] = sum_{k in [k0, k0+KC)} x[k] W[k][i]  (the transposed product of the backward; lanes = consecutive i)
+template <int KC>
+__device__ __forceinline__ float gemv_cols(const float* __restrict__ W, int ldw, const float* __restrict__ sx, int k0, int i) {
+    const float* w = W + (long)k0 * ldw + i;
+    float wv[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) wv[k] = gld(w + (long)k * ldw);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) acc += sx[k0 + k] * wv[k];
+    return acc;
+}
+
+// LayerNorm of one 64-wide row held one column per lane of a wave
+__device__ __forceinline__ void ln_row(float v, float eps, float& xhat, float& rstd) {
+    const float mean = group_sum<64>(v) * (1.0f / 64.0f);
+    const float dl = v - mean;
+    const float var = group_sum<64>(dl * dl) * (1.0f / 64.0f);
+    rstd = 1.0f / sqrtf(var + eps);
+    xhat = dl * rstd;
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+top_fwd_kernel(const TopFwdP P) {
+    constexpr int TS = 64 * FS;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sX = sm;                       // x tile
+    float* sK = sm + TS;                  // K tile [token][feature]
+    float* sV = sm + 2 * TS;              // V tile [token][feature]
+    float* sPart = sm + 3 * TS;           // DFT partials [16][4][2][64] = 8192 floats
+    float* sTab = sPart + 8192;           // FUSED_MAX_CB * 128
+    float* sSpec = sTab + FUSED_MAX_CB * 128;   // FUSED_MAX_CB * 128
+    float* sVec = sSpec + FUSED_MAX_CB * 128;   // row vectors: [0]=q [64]=pd(h*64) [320]=ctx [384]=hmix [448]=g(256) [704]=dsp
+    int* sIds = reinterpret_cast<int*>(sVec + 768);
+    float* sQ = sVec; float* sPd = sVec + 64; float* sCtx = sVec + 320; float* sHm = sVec + 384; float* sG = sVec + 448;
+    float* sDsp = sVec + 704;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int L = P.L, Lp = P.Lp, heads = P.heads, cb = P.cb;
+    const int b = blockIdx.x, tl = L - 1;
+    const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
+
+    // ---- load: x tile, ids, twiddles; K / V weight fragments for this wave's two 32 x 32 tiles
+    const int wm = wave >> 1, wn = wave & 1, col = wn * 32 + l31;
+    const long wrow = (long)col * 64 + 4 * half;
+    f32x4 wA[8], wB[8];
+    load_w8(P.wk + wrow, wA);
+    load_w8(P.wv + wrow, wB);
+    const float bias_k = gld(P.bk + col), bias_v = gld(P.bv + col);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+        f32x4 v = {0, 0, 0, 0};
+        if (r < L) v = gld4(P.X + (tok0 + r) * 64 + c4);
+        st4(sX + r * FS + c4, v);
+    }
+    if (tid < 64) sIds[tid] = tid < L ? gldi(P.ids32 + (tok0 + tid)) : 0;
+    build_twiddle_table(P.tw, L, cb, sTab);
+    lds_barrier();
+
+    // ---- K, V projections of all rows (MFMA), spectrum of x (VALU)
+    {
+        const int arow = (wm * 32 + l31) * FS + 4 * half;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_w8(sX + arow, wA, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sK[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + bias_k;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_w8(sX + arow, wB, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sV[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + bias_v;
+    }
+    auto xsrc = [&](int, int t, int lc) { return ld4(sX + t * FS + lc); };
+    dft_spectrum_tab<1>(xsrc, L, cb, sTab, sSpec, sPart);        // ends with a barrier: sK / sV complete too
+
+    // q_last = x_last . Wq^T + bq  (4 lanes per output), and the k, v rows -> global (the backward reads them)
+    {
+        const int n = tid >> 2, slice = tid & 3;
+        const float qv = gemv_rows<64, 4>(P.wq, 64, sX + tl * FS, n, slice) + gld(P.bq + n);
+        if (slice == 0) { sQ[n] = qv; gst(P.q + el + n, qv); }
+        const int lr = tid >> 4, lc = (tid & 15) << 2;
+        for (int r = lr; r < L; r += 16) {
+            gst4(P.k + (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
+            gst4(P.v + (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
+        }
+    }
+    // FrequencyLayer output of the last row (wave 0, lane = column):  src/model/bsarec.py:90-104
+    if (wave == 0) {
+        const int c = lane, c4 = c & ~3;
+        const f32x4 low4 = lowpass_tab(sSpec, tl, c4, L, cb, sTab);
+        const float low = (c & 3) == 0 ? low4.x : (c & 3) == 1 ? low4.y : (c & 3) == 2 ? low4.z : low4.w;
+        const float xv = sX[tl * FS + c];
+        gst(P.low + el + c, low);
+        const float bt = gld(P.sqrt_beta + c);
+        const float f = low + bt * bt * (xv - low);
+        const float v = f * drop_mult1(P.drop_f, (uint64_t)(el + c)) + xv;
+        float xh, rs;
+        ln_row(v, P.eps, xh, rs);
+        gst(P.xhat_f + el + c, xh);
+        if (c == 0) gst(P.rstd_f + tok0 + tl, rs);
+        sDsp[c] = gld(P.f_g + c) * xh + gld(P.f_b + c);
+    }
+    lds_barrier();
+
+    // ---- attention row of the last query: one wave per head, lane = key        src/model/_modules.py:118-135
+    if (wave < heads) {
+        const int head = wave, key = lane;
+        float s = -INFINITY;
+        if (key < L) {
+            float acc = 0.f;
+            const float* kr = sK + key * FS + head * DH;
+            const float* qr = sQ + head * DH;
+#pragma unroll
+            for (int c = 0; c < DH; c += 4) {
+                const f32x4 kv = ld4(kr + c), qv = ld4(qr + c);
+                acc += kv.x * qv.x + kv.y * qv.y + kv.z * qv.z + kv.w * qv.w;
+            }
+            s = acc / sqrtf((float)DH) + (sIds[key] > 0 ? 0.0f : -10000.0f);      // key <= query always holds for the last row
+        }
+        const float mx = group_max<64>(s);
+        const float e = key < L ? __expf(s - mx) : 0.f;
+        const float p = e / group_sum<64>(e);
+        const long pe = (((long)b * heads + head) * L + tl) * Lp;
+        if (key < Lp) gst(P.probs + pe + key, p);
+        sPd[head * 64 + key] = key < L ? p * drop_mult1(P.drop_p, (uint64_t)(pe + key)) : 0.f;
+    }
+    // dense weights while the softmax runs
+    const int on = tid >> 2, osl = tid & 3;
+    lds_barrier();
+    if (tid < 64) {                               // ctx_last[c] = sum_j Drop(p)_j v_j[c]
+        const int c = tid, head = c / DH;
+        float acc = 0.f;
+        for (int j = 0; j < L; ++j) acc += sPd[head * 64 + j] * sV[j * FS + c];
+        sCtx[c] = acc;
+        gst(P.ctx + el + c, acc);
+    }
+    lds_barrier();
+
+    // ---- dense + dropout + residual + LayerNorm + alpha mix (one row)
+    {
+        const float o = gemv_rows<64, 4>(P.wo, 64, sCtx, on, osl) + gld(P.bo + on);
+        if (osl == 0) sG[on] = o;
+    }
+    lds_barrier();
+    if (wave == 0) {
+        const int c = lane;
+        const float v = sG[c] * drop_mult1(P.drop_o, (uint64_t)(el + c)) + sX[tl * FS + c];
+        float xh, rs;
+        ln_row(v, P.eps, xh, rs);
+        gst(P.xhat_a + el + c, xh);
+        if (c == 0) gst(P.rstd_a + tok0 + tl, rs);
+        const float a = gld(P.a_g + c) * xh + gld(P.a_b + c);
+        const float hm = P.alpha * sDsp[c] + P.oma * a;
+        sHm[c] = hm;
+        gst(P.hmix + el + c, hm);
+    }
+    lds_barrier();
+
+    // ---- feed-forward (one row): u = hmix W1^T + b1 (one output per thread), y = gelu(u) W2^T + b2
+    {
+        const float u = gemv_rows<64, 1>(P.w1, 64, sHm, tid, 0) + gld(P.b1 + tid);
+        gst(P.u + (tok0 + tl) * 256 + tid, u);
+        sG[tid] = gelu_f(u);
+    }
+    lds_barrier();
+    {
+        const float y = gemv_rows<256, 4>(P.w2, 256, sG, on, osl) + gld(P.b2 + on);
+        if (osl == 0) sQ[on] = y;
+    }
+    lds_barrier();
+    if (wave == 0) {
+        const int c = lane;
+        const float v = sQ[c] * drop_mult1(P.drop_ff, (uint64_t)(el + c)) + sHm[c];
+        float xh, rs;
+        ln_row(v, P.eps, xh, rs);
+        gst(P.xhat_ff + el + c, xh);
+        if (c == 0) gst(P.rstd_ff + tok0 + tl, rs);
+        gst(P.Xout + el + c, gld(P.ff_g + c) * xh + gld(P.ff_b + c));
+    }
+}
+
+static inline size_t top_fwd_smem_bytes() { return (size_t)(3 * 64 * FS + 8192 + 2 * FUSED_MAX_CB * 128 + 768 + 64) * 4; }
+
+
+// =============================================================================================
+// backward of the top block (see the header comment): no matrix product is left, only vector chains
+// =============================================================================================
+struct TopBwdP {
+    float* dX; const float* X;
+    const float *sqrt_beta, *f_g, *wq, *wk, *wv, *wo, *a_g, *w1, *w2, *ff_g;
+    const float* tw;
+    const float *xhat_f, *rstd_f, *q, *k, *v, *probs, *xhat_a, *rstd_a, *u, *xhat_ff, *rstd_ff, *low;
+    const float* dh_slabs; int dh_nsplit; long dh_stride;   // dY of row L-1 = sum of the logits backward's split-K slabs [s][B][64]
+    float *dT, *dU, *dO, *dq;                                // last rows: operands of the last-position weight-gradient products
+    float *ak, *rk, *av, *rv;                                // [B * heads][64]: dWk = AK^T RK, dWv = AV^T RV
+    float *pbk, *pbv;                                        // [B][64] key / value bias-gradient partials
+    float *pg_ff, *pb_ff, *pg_a, *pb_a, *pg_f, *pb_f, *pbeta;   // [B][64] LayerNorm / sqrt_beta partials
+    int L, Lp, cb, heads;
+    float alpha, oma;
+    DropP drop_f, drop_p, drop_o, drop_ff;
+};
+
+// LayerNorm backward of one row, one column per lane: returns dz; g = dy * gamma
+__device__ __forceinline__ float ln_row_bwd(float dy, float gamma, float xhat, float rstd) {
+    const float g = dy * gamma;
+    const float m1 = group_sum<64>(g) * (1.0f / 64.0f);
+    const float m2 = group_sum<64>(g * xhat) * (1.0f / 64.0f);
+    return rstd * (g - m1 - xhat * m2);
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256)
+top_bwd_kernel(const TopBwdP P) {
+    constexpr int TS = 64 * FS;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sX = sm;
+    float* sK = sm + TS;
+    float* sV = sm + 2 * TS;
+    float* sTab = sm + 3 * TS;                  // FUSED_MAX_CB * 128
+    float* sVec = sTab + FUSED_MAX_CB * 128;
+    float* sDT = sVec;            // 64   dT2 (grad of the dense_2 output)
+    float* sDU = sVec + 64;       // 256  dU
+    float* sRed = sVec + 320;     // 256  partial sums [4][64]
+    float* sDH = sVec + 576;      // 64   grad of hmix
+    float* sDO = sVec + 640;      // 64
+    float* sDF = sVec + 704;      // 64   (1 - beta^2) dF  (beta^2 dF is folded into sLast)
+    float* sLast = sVec + 768;    // 64   extra gradient of the last row: dzA + dzF + beta^2 dF (+ dq Wq later)
+    float* sDC = sVec + 832;      // 64
+    float* sQ = sVec + 896;       // 64   q_last
+    float* sDQ = sVec + 960;      // 64
+    float* sDs = sVec + 1024;     // [4][64] ds per head
+    float* sPd = sVec + 1280;     // [4][64] Drop(p) per head
+    float* sQK = sVec + 1536;     // [4][64] q_h Wk_h
+    float* sCV = sVec + 1792;     // [4][64] dC_h Wv_h
+    float* sPl = sVec + 2048;     // 64   low-pass projector column P[j][L-1]
+    float* sSum = sVec + 2112;    // [2][4] sum_j ds, sum_j Drop(p) per head
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = P.L, Lp = P.Lp, heads = P.heads, cb = P.cb;
+    const int b = blockIdx.x, tl = L - 1;
+    const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
+
+    // ---- tiles and the upstream gradient
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+        f32x4 x = {0, 0, 0, 0}, k = x, v = x;
+        if (r < L) { x = gld4(P.X + (tok0 + r) * 64 + c4); k = gld4(P.k + (tok0 + r) * 64 + c4); v = gld4(P.v + (tok0 + r) * 64 + c4); }
+        st4(sX + r * FS + c4, x); st4(sK + r * FS + c4, k); st4(sV + r * FS + c4, v);
+    }
+    build_twiddle_table(P.tw, L, cb, sTab);
+    const float u_mine = gld(P.u + (tok0 + tl) * 256 + tid);
+    if (tid < 64) sQ[tid] = gld(P.q + el + tid);
+    float dz_ff = 0.f;
+    if (wave == 0) {            // FeedForward LayerNorm backward (row L-1)
+        const int c = lane;
+        float dy = 0.f;
+        for (int sp = 0; sp < P.dh_nsplit; ++sp) dy += gld(P.dh_slabs + sp * P.dh_stride + (long)b * 64 + c);
+        const float xh = gld(P.xhat_ff + el + c);
+        dz_ff = ln_row_bwd(dy, gld(P.ff_g + c), xh, gld(P.rstd_ff + tok0 + tl));
+        gst(P.pg_ff + (long)b * 64 + c, dy * xh);
+        gst(P.pb_ff + (long)b * 64 + c, dy);
+        const float dt = dz_ff * drop_mult1(P.drop_ff, (uint64_t)(el + c));
+        sDT[c] = dt;
+        gst(P.dT + el + c, dt);
+    }
+    lds_barrier();
+
+    // ---- dU = (dT2 . W2) * gelu'(u)   (one of the 256 inner units per thread)
+    {
+        const float du = gemv_cols<64>(P.w2, 256, sDT, 0, tid) * gelu_grad_f(u_mine);
+        sDU[tid] = du;
+        gst(P.dU + (tok0 + tl) * 256 + tid, du);
+    }
+    lds_barrier();
+    // ---- d(hmix) = dU . W1 + dz   (4 slices of 64 inner units)
+    sRed[wave * 64 + lane] = gemv_cols<64>(P.w1, 64, sDU, 64 * wave, lane);
+    lds_barrier();
+    if (wave == 0) {
+        const int c = lane;
+        const float dh = (sRed[c] + sRed[64 + c]) + (sRed[128 + c] + sRed[192 + c]) + dz_ff;
+        // alpha mix + the two LayerNorm backwards (attention branch scaled by 1 - alpha, filter branch by alpha)
+        const float dya = P.oma * dh, dyf = P.alpha * dh;
+        const float xa = gld(P.xhat_a + el + c), xf = gld(P.xhat_f + el + c);
+        const float dza = ln_row_bwd(dya, gld(P.a_g + c), xa, gld(P.rstd_a + tok0 + tl));
+        const float dzf = ln_row_bwd(dyf, gld(P.f_g + c), xf, gld(P.rstd_f + tok0 + tl));
+        gst(P.pg_a + (long)b * 64 + c, dya * xa); gst(P.pb_a + (long)b * 64 + c, dya);
+        gst(P.pg_f + (long)b * 64 + c, dyf * xf); gst(P.pb_f + (long)b * 64 + c, dyf);
+        const float dO = dza * drop_mult1(P.drop_o, (uint64_t)(el + c));
+        const float dF = dzf * drop_mult1(P.drop_f, (uint64_t)(el + c));
+        sDO[c] = dO;
+        gst(P.dO + el + c, dO);
+        const float bt = gld(P.sqrt_beta + c), b2 = bt * bt;
+        sDF[c] = (1.0f - b2) * dF;
+        sLast[c] = dza + dzf + b2 * dF;
+        // d sqrt_beta: f = low + beta^2 (x - low)
+        gst(P.pbeta + (long)b * 64 + c, 2.0f * bt * dF * (sX[tl * FS + c] - gld(P.low + el + c)));
+        // column L-1 of the low-pass projector: P[j][L-1] = (1/L) sum_k w_k cos(2 pi k (j - (L-1)) / L)
+        float pl = 0.f;
+        if (c < L)
+            for (int k = 0; k < cb; ++k) {
+                const float w = (k == 0 || 2 * k == L) ? 1.0f : 2.0f;
+                pl += w * (sTab[2 * (k * 64 + c)] * sTab[2 * (k * 64 + tl)] + sTab[2 * (k * 64 + c) + 1] * sTab[2 * (k * 64 + tl) + 1]);
+            }
+        sPl[c] = pl / (float)L;
+    }
+    lds_barrier();
+    // ---- dC = dO . Wo   (4 slices of 16 output features)
+    sRed[wave * 64 + lane] = gemv_cols<16>(P.wo, 64, sDO, 16 * wave, lane);
+    lds_barrier();
+    if (tid < 64) sDC[tid] = (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
+    lds_barrier();
+
+    // ---- attention backward of the last query: one wave per head, lane = key
+    if (wave < heads) {
+        const int head = wave, key = lane;
+        float dpd = 0.f, p = 0.f, mp = 0.f;
+        if (key < L) {
+            const float* vr = sV + key * FS + head * DH;
+            const float* dc = sDC + head * DH;
+#pragma unroll
+            for (int c = 0; c < DH; c += 4) {
+                const f32x4 vv = ld4(vr + c), dv = ld4(dc + c);
+                dpd += vv.x * dv.x + vv.y * dv.y + vv.z * dv.z + vv.w * dv.w;
+            }
+            const long pe = (((long)b * heads + head) * L + tl) * Lp + key;
+            p = gld(P.probs + pe);
+            mp = drop_mult1(P.drop_p, (uint64_t)pe);
+        }
+        const float dp = dpd * mp;
+        const float delta = group_sum<64>(p * dp);
+        const float ds = p * (dp - delta) / sqrtf((float)DH);
+        const float pd = p * mp;
+        sDs[head * 64 + key] = ds;
+        sPd[head * 64 + key] = pd;
+        const float s1 = group_sum<64>(ds), s2 = group_sum<64>(pd);
+        if (key == 0) { sSum[head] = s1; sSum[4 + head] = s2; }
+    }
+    lds_barrier();
+    // ---- per-head vectors: dq, the weight-gradient operands of key / value, q_h Wk_h, dC_h Wv_h
+    if (tid < 64) {
+        const int c = tid, head = c / DH;
+        float acc = 0.f;
+        for (int j = 0; j < L; ++j) acc += sDs[head * 64 + j] * sK[j * FS + c];
+        sDQ[c] = acc;
+        gst(P.dq + el + c, acc);
+        gst(P.pbk + (long)b * 64 + c, sQ[c] * sSum[head]);
+        gst(P.pbv + (long)b * 64 + c, sDC[c] * sSum[4 + head]);
+    }
+    for (int o = tid; o < heads * 64; o += 256) {
+        const int head = o >> 6, i = o & 63;
+        float rk = 0.f, rv = 0.f;
+        for (int j = 0; j < L; ++j) { const float x = sX[j * FS + i]; rk += sDs[head * 64 + j] * x; rv += sPd[head * 64 + j] * x; }
+        const long e = ((long)b * heads + head) * 64 + i;
+        const bool mine = i / DH == head;
+        gst(P.rk + e, rk); gst(P.rv + e, rv);
+        gst(P.ak + e, mine ? sQ[i] : 0.f); gst(P.av + e, mine ? sDC[i] : 0.f);
+        sQK[o] = gemv_cols<DH>(P.wk, 64, sQ, head * DH, i);
+        sCV[o] = gemv_cols<DH>(P.wv, 64, sDC, head * DH, i);
+    }
+    lds_barrier();
+    // dq . Wq joins the last row's extra gradient (4 slices of 16 features)
+    sRed[wave * 64 + lane] = gemv_cols<16>(P.wq, 64, sDQ, 16 * wave, lane);
+    lds_barrier();
+    if (tid < 64) sLast[tid] += (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
+    lds_barrier();
+    // ---- dX, all rows
+    {
+        const int lr = tid >> 4, lc = (tid & 15) << 2;
+        const f32x4 df = ld4(sDF + lc);
+        for (int j = lr; j < L; j += 16) {
+            f32x4 dx = df * sPl[j];
+            for (int h = 0; h < heads; ++h)
+                dx += ld4(sQK + h * 64 + lc) * sDs[h * 64 + j] + ld4(sCV + h * 64 + lc) * sPd[h * 64 + j];
+            if (j == tl) dx += ld4(sLast + lc);
+            gst4(P.dX + (tok0 + j) * 64 + lc, dx);
+        }
+    }
+}
+
+static inline size_t top_bwd_smem_bytes() { return (size_t)(3 * 64 * FS + FUSED_MAX_CB * 128 + 2176) * 4; }

@@ -109,7 +109,7 @@ class _LossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, ids, answers, *params):
-        plan = model._run_forward(ids, train=model.training, new_step=model.training)
+        plan = model._run_forward(ids, train=model.training, new_step=model.training, last_only=True)
         model._run_loss(plan, answers)
         ctx.model, ctx.plan = model, plan
         return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
@@ -245,7 +245,7 @@ class BSARecModel(nn.Module):
     def _stream(self):
         return torch.cuda.current_stream(self._arena.device).cuda_stream
 
-    def _run_forward(self, input_ids, train: bool, new_step: bool) -> _Plan:
+    def _run_forward(self, input_ids, train: bool, new_step: bool, last_only: bool = False) -> _Plan:
         if input_ids.dim() != 2 or input_ids.shape[1] != self.args.max_seq_length:
             raise ValueError("input_ids must be [B, max_seq_length]")
         ids = input_ids.to(device=self._arena.device, dtype=torch.int64).contiguous()
@@ -253,7 +253,9 @@ class BSARecModel(nn.Module):
         lib, st = plan.lib, self._stream()
         if new_step:
             L.check(lib.bsarec_step_begin(plan.handle, st), "bsarec_step_begin")
-        L.check(lib.bsarec_forward(plan.handle, ids.data_ptr(), 1 if train else 0, st), "bsarec_forward")
+        # last_only: the caller consumes position L-1 of the last layer only (loss / logits / backward)
+        fwd = lib.bsarec_forward_last if last_only else lib.bsarec_forward
+        L.check(fwd(plan.handle, ids.data_ptr(), 1 if train else 0, st), "bsarec_forward")
         plan._ids_keepalive = ids
         return plan
 
@@ -283,14 +285,14 @@ class BSARecModel(nn.Module):
         """src/model/bsarec.py:30-37: 0-d loss tensor; ``.backward()`` fills every parameter's grad."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return _LossFn.apply(self, input_ids, answers, *self.parameters())
-        plan = self._run_forward(input_ids, train=self.training, new_step=self.training)
+        plan = self._run_forward(input_ids, train=self.training, new_step=self.training, last_only=True)
         self._run_loss(plan, answers)
         return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
 
     def full_logits(self, input_ids) -> torch.Tensor:
         """Last-position scores over the whole catalogue (Trainer.predict_full of the last position,
         src/trainers.py:62-68,126-129) without leaving the device."""
-        plan = self._run_forward(input_ids, train=False, new_step=False)
+        plan = self._run_forward(input_ids, train=False, new_step=False, last_only=True)
         L.check(plan.lib.bsarec_logits(plan.handle, self._stream()), "bsarec_logits")
         V = self.args.item_size
         Vp = (V + 3) // 4 * 4

@@ -112,6 +112,14 @@ int bsarec_forward(bsarec_plan_t *plan, const int64_t *ids, int train, void *str
  * logits = h[:, -1, :] @ E^T, mean CE against answers int64[B]; also prepares dlogits. */
 int bsarec_loss(bsarec_plan_t *plan, const int64_t *answers, void *stream);
 
+/* bsarec_forward for callers that consume only position L-1 of the last layer -- bsarec_loss, bsarec_logits and
+ * bsarec_backward, i.e. calculate_loss (src/model/bsarec.py:30-37) and Trainer.predict_full of the last position
+ * (src/trainers.py:126-129).  At the fused shape with >= 2 layers the top block is then evaluated on that row only
+ * (it still attends to all positions) and its backward uses the exact one-row structure of the upstream gradient;
+ * loss, logits and all parameter gradients are those of bsarec_forward.  Other rows of BSAREC_BUF_LAYER_OUT[N] are
+ * left unspecified.  BSAREC_PRUNE_TOP=0 makes this identical to bsarec_forward. */
+int bsarec_forward_last(bsarec_plan_t *plan, const int64_t *ids, int train, void *stream);
+
 /* logits only (Trainer.predict_full, src/trainers.py:62-68). */
 int bsarec_logits(bsarec_plan_t *plan, void *stream);
 
@@ -174,6 +182,9 @@ int bsarec_profile_select(int kclass);
 /* Use (1, default) or bypass (0) the fused per-sequence BSARecBlock kernels that exist for hidden = 64,
  * L <= 64, cutoff_bins <= 8; other shapes always take the generic tiled kernels.  Process-wide. */
 int bsarec_set_fused(int enable);
+/* Allow (1, default) or forbid (0) the one-row evaluation of the top block in bsarec_forward_last.  Process-wide; read
+ * when a plan is created (env BSAREC_PRUNE_TOP=0 forbids it too). */
+int bsarec_set_prune_top(int enable);
 /* Diagnostic: device buffer of 32*2*layers int64 that receives per-phase shader-clock stamps of workgroup 0
  * of the fused kernels (null disables). */
 int bsarec_debug_stamps(void *dev_buf);

@@ -97,10 +97,23 @@ def test_three_fused_adam_steps_vs_reference(name):
         assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - a).max())
 
 
+@pytest.mark.parametrize("prune", [1, 0])
 @pytest.mark.parametrize("name,B", [("A_d64_L50_h2", 37), ("C_d32_L12_h4", 70), ("D_d128_L200_h4", 5)])
-def test_dropout_training_step_vs_oracle(name, B):
+def test_dropout_training_step_vs_oracle(name, B, prune):
     """Dropout ON (p = 0.5 / 0.3): the oracle draws the same Philox masks, so forward, loss and every
-    gradient must agree; ragged batch sizes exercise the tile tails."""
+    gradient must agree; ragged batch sizes exercise the tile tails.  prune = 1: the loss path evaluates the top
+    block on its last row only (fused shape), so of the last layer's output only that row is compared; prune = 0:
+    the full block kernels, every row compared."""
+    from oracle import bsarec_oracle as O
+    from bsarec_amd import _lib as Lb0
+    Lb0.load().bsarec_set_prune_top(prune)
+    try:
+        _dropout_training_step_vs_oracle(name, B, prune)
+    finally:
+        Lb0.load().bsarec_set_prune_top(1)
+
+
+def _dropout_training_step_vs_oracle(name, B, prune):
     from oracle import bsarec_oracle as O
     cfg, params, _, _, _ = load_e2e(name)
     cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob = 0.5, 0.3
@@ -123,6 +136,8 @@ def test_dropout_training_step_vs_oracle(name, B):
     from bsarec_amd import _lib as Lb
     got = [plan.view(Lb.BUF_LAYER_OUT, l, (B, L, cfg.hidden_size)).cpu().numpy() for l in range(cfg.num_hidden_layers + 1)]
     for i, (g, r) in enumerate(zip(got, outs)):
+        if prune and i == cfg.num_hidden_layers:
+            g, r = g[:, -1], r[:, -1]
         assert np.abs(g - r).max() <= 1e-3, (i, np.abs(g - r).max())
         assert rel_l2(g, r) <= 2e-5, (i, rel_l2(g, r))
     assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
@@ -146,14 +161,17 @@ def test_eval_mode_ignores_dropout_and_is_deterministic():
 
 
 @pytest.mark.parametrize("heads,L,B", [(1, 50, 9), (2, 50, 33), (4, 50, 5), (2, 64, 3), (2, 20, 7), (4, 33, 6)])
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [2, 1, 0])
 def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
-    """hidden = 64, L <= 64 takes the fused per-sequence BSARecBlock kernels; the same cases are also forced
-    through the generic tiled kernels.  Both must match the oracle (dropout on, shared Philox masks)."""
+    """hidden = 64, L <= 64 takes the fused per-sequence BSARecBlock kernels (fused = 2: with the top block of the
+    loss path evaluated on its last row only, fused = 1: full block kernels for both layers); the same cases are also
+    forced through the generic tiled kernels (fused = 0).  All must match the oracle (dropout on, shared Philox
+    masks): loss and every parameter gradient; layer outputs on every row the variant produces."""
     from oracle import bsarec_oracle as O
     from bsarec_amd import _lib as Lb
     lib = Lb.load()
-    lib.bsarec_set_fused(fused)
+    lib.bsarec_set_fused(1 if fused else 0)
+    lib.bsarec_set_prune_top(1 if fused == 2 else 0)
     try:
         cfg = O.Config(item_size=131, hidden_size=64, max_seq_length=L, num_hidden_layers=2, num_attention_heads=heads,
                        c=5, alpha=0.7, hidden_dropout_prob=0.4, attention_probs_dropout_prob=0.3)
@@ -178,11 +196,14 @@ def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
         oloss, _, G, outs = O.loss_and_grads(params, cfg, ids, ans, O.DropoutSpec(True, 77, 1))
         plan = model._plan(B)
         for l in range(3):
-            g = plan.view(Lb.BUF_LAYER_OUT, l, (B, L, 64)).cpu().numpy()
+            g, r = plan.view(Lb.BUF_LAYER_OUT, l, (B, L, 64)).cpu().numpy(), outs[l]
+            if fused == 2 and l == 2:
+                g, r = g[:, -1], r[:, -1]
             assert np.isfinite(g).all()
-            assert rel_l2(g, outs[l]) <= 2e-5, (l, rel_l2(g, outs[l]))
-            assert np.abs(g - outs[l]).max() <= 1e-3, (l, np.abs(g - outs[l]).max())
+            assert rel_l2(g, r) <= 2e-5, (l, rel_l2(g, r))
+            assert np.abs(g - r).max() <= 1e-3, (l, np.abs(g - r).max())
         assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
         check_grads(model, G, tol=2e-4)
     finally:
         lib.bsarec_set_fused(1)
+        lib.bsarec_set_prune_top(1)
