@@ -64,6 +64,10 @@ def cpu_baseline(a, budget_s=12.0):
                       f"numpy oracle with BLAS threads on all host cores, {dt:.1f} s"}
 
 
+def fused_shape(a):
+    return a.hidden == 64 and a.seq_len <= 64
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +179,39 @@ def main():
                               else " (grad graph + eager RCCL all-reduce + Adam graph)" if pg is not None and use_graph else ""),
                    "final_loss": round(final_loss, 4)},
     }
+    out["config"]["top_block"] = ("loss path evaluates the top BSARecBlock on position L-1 only (it still attends to every "
+                                  "position); exact, same loss and gradients (SURVEY C.6); FLOP-based fractions below use the "
+                                  "un-pruned counts") if getattr(model, "_plans", None) is not None and fused_shape(a) and a.layers >= 2 and \
+        os.environ.get("BSAREC_PRUNE_TOP", "1") != "0" else "full"
+    if rank == 0 and world == 1 and out["config"]["top_block"] != "full" and not a.no_roofline:
+        # the same step with the FULL top-block kernels (nothing uses the one-row structure), measured in this run
+        Lb.load().bsarec_set_prune_top(0)
+        try:
+            torch.manual_seed(42)
+            model2 = BSARecModel(margs).to(dev)
+            model2.set_seed(42, rank)
+            model2.train()
+            batches2 = D.DeviceBatches(users, inputs, answers, a.batch, dev, shuffle=True, seed=42, rank=rank, world=world)
+            trainer2 = Trainer(model2, batches2, None, None, margs, None, use_graph=not a.no_graph, process_group=pg)
+            perm2 = batches2.local_permutation()
+            nfull = (perm2.shape[0] // B) * B
+            pbuf2 = torch.zeros(len(answers), dtype=torch.int64, device=dev)
+            pbuf2[:perm2.shape[0]].copy_(perm2)
+            cur2 = torch.zeros(1, dtype=torch.int64, device=dev)
+            nst = min(a.steps, nfull // B - max(a.warmup, 1) - 1)
+            for _ in range(max(a.warmup, 1)):
+                trainer2.indexed_step(batches2, pbuf2, cur2, None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nst):
+                l2 = trainer2.indexed_step(batches2, pbuf2, cur2, None)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            assert np.isfinite(float(l2.item()))
+            out["full_top_block"] = {"value": round(a.batch * nst / dt2, 1), "ms_per_step": round(1e3 * dt2 / nst, 4), "steps": nst}
+            del trainer2, model2, batches2
+        finally:
+            Lb.load().bsarec_set_prune_top(1)
     flops_seq = train_flops_per_seq(a)
     out["step_mfma_frac"] = round(flops_seq * a.batch * world * a.steps / dt / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 5)
 

@@ -30,18 +30,20 @@ __device__ __forceinline__ float drop_mult1(const DropP& d, uint64_t e) {
     return j == 0 ? m.x : j == 1 ? m.y : j == 2 ? m.z : m.w;
 }
 
-// y[n] = sum_k W[n][k] x[k]  (nn.Linear forward, W row-major [*][ldw]); KS adjacent lanes share one output
+// y[n] = sum_k W[n][k] x[k]  (nn.Linear forward, W row-major [*][ldw]); KS adjacent lanes share one output.
+// Split in load / dot so that the weight rows of a later step are requested early and their L2 round trip is hidden.
 template <int K, int KS>
-__device__ __forceinline__ float gemv_rows(const float* __restrict__ W, int ldw, const float* __restrict__ sx, int n, int slice) {
-    constexpr int KC = K / KS;
-    const float* w = W + (long)n * ldw + slice * KC;
-    const float* x = sx + slice * KC;
-    f32x4 wv[KC / 4];
+__device__ __forceinline__ void gemv_rows_load(const float* __restrict__ W, int ldw, int n, int slice, f32x4 (&wv)[K / KS / 4]) {
+    const float* w = W + (long)n * ldw + slice * (K / KS);
 #pragma unroll
-    for (int i = 0; i < KC / 4; ++i) wv[i] = gld4(w + 4 * i);
+    for (int i = 0; i < K / KS / 4; ++i) wv[i] = gld4(w + 4 * i);
+}
+template <int K, int KS>
+__device__ __forceinline__ float gemv_rows_dot(const f32x4 (&wv)[K / KS / 4], const float* __restrict__ sx, int slice) {
+    const float* x = sx + slice * (K / KS);
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < KC / 4; ++i) {
+    for (int i = 0; i < K / KS / 4; ++i) {
         const f32x4 xv = ld4(x + 4 * i);
         acc += wv[i].x * xv.x + wv[i].y * xv.y + wv[i].z * xv.z + wv[i].w * xv.w;
     }
@@ -54,11 +56,13 @@ __device__ __forceinline__ float gemv_rows(const float* __restrict__ W, int ldw,
 
 // y[i] = sum_{k in [k0, k0+KC)} x[k] W[k][i]  (the transposed product of the backward; lanes = consecutive i)
 template <int KC>
-__device__ __forceinline__ float gemv_cols(const float* __restrict__ W, int ldw, const float* __restrict__ sx, int k0, int i) {
+__device__ __forceinline__ void gemv_cols_load(const float* __restrict__ W, int ldw, int k0, int i, float (&wv)[KC]) {
     const float* w = W + (long)k0 * ldw + i;
-    float wv[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) wv[k] = gld(w + (long)k * ldw);
+}
+template <int KC>
+__device__ __forceinline__ float gemv_cols_dot(const float (&wv)[KC], const float* __restrict__ sx, int k0) {
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < KC; ++k) acc += sx[k0 + k] * wv[k];
@@ -110,6 +114,12 @@ top_fwd_kernel(const TopFwdP P) {
         if (r < L) v = gld4(P.X + (tok0 + r) * 64 + c4);
         st4(sX + r * FS + c4, v);
     }
+    // weight rows of the one-row products, requested now (query, dense) and after the MFMA phase (feed-forward)
+    const int on = tid >> 2, osl = tid & 3;
+    f32x4 wq4[4], wo4[4];
+    gemv_rows_load<64, 4>(P.wq, 64, on, osl, wq4);
+    gemv_rows_load<64, 4>(P.wo, 64, on, osl, wo4);
+    const float bq_n = gld(P.bq + on), bo_n = gld(P.bo + on), b1_n = gld(P.b1 + tid), b2_n = gld(P.b2 + on);
     if (tid < 64) sIds[tid] = tid < L ? gldi(P.ids32 + (tok0 + tid)) : 0;
     build_twiddle_table(P.tw, L, cb, sTab);
     lds_barrier();
@@ -129,14 +139,16 @@ top_fwd_kernel(const TopFwdP P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sV[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + bias_v;
     }
+    f32x4 w1r[16], w2r[16];
+    gemv_rows_load<64, 1>(P.w1, 64, tid, 0, w1r);
+    gemv_rows_load<256, 4>(P.w2, 256, on, osl, w2r);
     auto xsrc = [&](int, int t, int lc) { return ld4(sX + t * FS + lc); };
     dft_spectrum_tab<1>(xsrc, L, cb, sTab, sSpec, sPart);        // ends with a barrier: sK / sV complete too
 
     // q_last = x_last . Wq^T + bq  (4 lanes per output), and the k, v rows -> global (the backward reads them)
     {
-        const int n = tid >> 2, slice = tid & 3;
-        const float qv = gemv_rows<64, 4>(P.wq, 64, sX + tl * FS, n, slice) + gld(P.bq + n);
-        if (slice == 0) { sQ[n] = qv; gst(P.q + el + n, qv); }
+        const float qv = gemv_rows_dot<64, 4>(wq4, sX + tl * FS, osl) + bq_n;
+        if (osl == 0) { sQ[on] = qv; gst(P.q + el + on, qv); }
         const int lr = tid >> 4, lc = (tid & 15) << 2;
         for (int r = lr; r < L; r += 16) {
             gst4(P.k + (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
@@ -152,7 +164,7 @@ top_fwd_kernel(const TopFwdP P) {
         gst(P.low + el + c, low);
         const float bt = gld(P.sqrt_beta + c);
         const float f = low + bt * bt * (xv - low);
-        const float v = f * drop_mult1(P.drop_f, (uint64_t)(el + c)) + xv;
+        const float v = f * drop_mult1(KARG(TopFwdP, drop_f), (uint64_t)(el + c)) + xv;
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
         gst(P.xhat_f + el + c, xh);
@@ -181,10 +193,8 @@ top_fwd_kernel(const TopFwdP P) {
         const float p = e / group_sum<64>(e);
         const long pe = (((long)b * heads + head) * L + tl) * Lp;
         if (key < Lp) gst(P.probs + pe + key, p);
-        sPd[head * 64 + key] = key < L ? p * drop_mult1(P.drop_p, (uint64_t)(pe + key)) : 0.f;
+        sPd[head * 64 + key] = key < L ? p * drop_mult1(KARG(TopFwdP, drop_p), (uint64_t)(pe + key)) : 0.f;
     }
-    // dense weights while the softmax runs
-    const int on = tid >> 2, osl = tid & 3;
     lds_barrier();
     if (tid < 64) {                               // ctx_last[c] = sum_j Drop(p)_j v_j[c]
         const int c = tid, head = c / DH;
@@ -197,13 +207,13 @@ top_fwd_kernel(const TopFwdP P) {
 
     // ---- dense + dropout + residual + LayerNorm + alpha mix (one row)
     {
-        const float o = gemv_rows<64, 4>(P.wo, 64, sCtx, on, osl) + gld(P.bo + on);
+        const float o = gemv_rows_dot<64, 4>(wo4, sCtx, osl) + bo_n;
         if (osl == 0) sG[on] = o;
     }
     lds_barrier();
     if (wave == 0) {
         const int c = lane;
-        const float v = sG[c] * drop_mult1(P.drop_o, (uint64_t)(el + c)) + sX[tl * FS + c];
+        const float v = sG[c] * drop_mult1(KARG(TopFwdP, drop_o), (uint64_t)(el + c)) + sX[tl * FS + c];
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
         gst(P.xhat_a + el + c, xh);
@@ -217,19 +227,19 @@ top_fwd_kernel(const TopFwdP P) {
 
     // ---- feed-forward (one row): u = hmix W1^T + b1 (one output per thread), y = gelu(u) W2^T + b2
     {
-        const float u = gemv_rows<64, 1>(P.w1, 64, sHm, tid, 0) + gld(P.b1 + tid);
+        const float u = gemv_rows_dot<64, 1>(w1r, sHm, 0) + b1_n;
         gst(P.u + (tok0 + tl) * 256 + tid, u);
         sG[tid] = gelu_f(u);
     }
     lds_barrier();
     {
-        const float y = gemv_rows<256, 4>(P.w2, 256, sG, on, osl) + gld(P.b2 + on);
+        const float y = gemv_rows_dot<256, 4>(w2r, sG, osl) + b2_n;
         if (osl == 0) sQ[on] = y;
     }
     lds_barrier();
     if (wave == 0) {
         const int c = lane;
-        const float v = sQ[c] * drop_mult1(P.drop_ff, (uint64_t)(el + c)) + sHm[c];
+        const float v = sQ[c] * drop_mult1(KARG(TopFwdP, drop_ff), (uint64_t)(el + c)) + sHm[c];
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
         gst(P.xhat_ff + el + c, xh);
@@ -308,6 +318,10 @@ top_bwd_kernel(const TopBwdP P) {
         st4(sX + r * FS + c4, x); st4(sK + r * FS + c4, k); st4(sV + r * FS + c4, v);
     }
     build_twiddle_table(P.tw, L, cb, sTab);
+    // weight columns of the vector products, requested up front: dense_2 / dense_1 now, the small ones after the first step
+    float w2c[64], w1c[64];
+    gemv_cols_load<64>(P.w2, 256, 0, tid, w2c);
+    gemv_cols_load<64>(P.w1, 64, 64 * wave, lane, w1c);
     const float u_mine = gld(P.u + (tok0 + tl) * 256 + tid);
     if (tid < 64) sQ[tid] = gld(P.q + el + tid);
     float dz_ff = 0.f;
@@ -319,7 +333,7 @@ top_bwd_kernel(const TopBwdP P) {
         dz_ff = ln_row_bwd(dy, gld(P.ff_g + c), xh, gld(P.rstd_ff + tok0 + tl));
         gst(P.pg_ff + (long)b * 64 + c, dy * xh);
         gst(P.pb_ff + (long)b * 64 + c, dy);
-        const float dt = dz_ff * drop_mult1(P.drop_ff, (uint64_t)(el + c));
+        const float dt = dz_ff * drop_mult1(KARG(TopBwdP, drop_ff), (uint64_t)(el + c));
         sDT[c] = dt;
         gst(P.dT + el + c, dt);
     }
@@ -327,13 +341,19 @@ top_bwd_kernel(const TopBwdP P) {
 
     // ---- dU = (dT2 . W2) * gelu'(u)   (one of the 256 inner units per thread)
     {
-        const float du = gemv_cols<64>(P.w2, 256, sDT, 0, tid) * gelu_grad_f(u_mine);
+        const float du = gemv_cols_dot<64>(w2c, sDT, 0) * gelu_grad_f(u_mine);
         sDU[tid] = du;
         gst(P.dU + (tok0 + tl) * 256 + tid, du);
     }
     lds_barrier();
     // ---- d(hmix) = dU . W1 + dz   (4 slices of 64 inner units)
-    sRed[wave * 64 + lane] = gemv_cols<64>(P.w1, 64, sDU, 64 * wave, lane);
+    float woc[16], wqc[16], wkc[DH], wvc[DH];
+    gemv_cols_load<16>(P.wo, 64, 16 * wave, lane, woc);
+    gemv_cols_load<16>(P.wq, 64, 16 * wave, lane, wqc);
+    const bool hv = tid < heads * 64;             // thread (head = wave, i = lane) of the per-head vector products
+    gemv_cols_load<DH>(P.wk, 64, (hv ? wave : 0) * DH, lane, wkc);
+    gemv_cols_load<DH>(P.wv, 64, (hv ? wave : 0) * DH, lane, wvc);
+    sRed[wave * 64 + lane] = gemv_cols_dot<64>(w1c, sDU, 64 * wave);
     lds_barrier();
     if (wave == 0) {
         const int c = lane;
@@ -345,8 +365,8 @@ top_bwd_kernel(const TopBwdP P) {
         const float dzf = ln_row_bwd(dyf, gld(P.f_g + c), xf, gld(P.rstd_f + tok0 + tl));
         gst(P.pg_a + (long)b * 64 + c, dya * xa); gst(P.pb_a + (long)b * 64 + c, dya);
         gst(P.pg_f + (long)b * 64 + c, dyf * xf); gst(P.pb_f + (long)b * 64 + c, dyf);
-        const float dO = dza * drop_mult1(P.drop_o, (uint64_t)(el + c));
-        const float dF = dzf * drop_mult1(P.drop_f, (uint64_t)(el + c));
+        const float dO = dza * drop_mult1(KARG(TopBwdP, drop_o), (uint64_t)(el + c));
+        const float dF = dzf * drop_mult1(KARG(TopBwdP, drop_f), (uint64_t)(el + c));
         sDO[c] = dO;
         gst(P.dO + el + c, dO);
         const float bt = gld(P.sqrt_beta + c), b2 = bt * bt;
@@ -365,7 +385,7 @@ top_bwd_kernel(const TopBwdP P) {
     }
     lds_barrier();
     // ---- dC = dO . Wo   (4 slices of 16 output features)
-    sRed[wave * 64 + lane] = gemv_cols<16>(P.wo, 64, sDO, 16 * wave, lane);
+    sRed[wave * 64 + lane] = gemv_cols_dot<16>(woc, sDO, 16 * wave);
     lds_barrier();
     if (tid < 64) sDC[tid] = (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
     lds_barrier();
@@ -384,7 +404,7 @@ top_bwd_kernel(const TopBwdP P) {
             }
             const long pe = (((long)b * heads + head) * L + tl) * Lp + key;
             p = gld(P.probs + pe);
-            mp = drop_mult1(P.drop_p, (uint64_t)pe);
+            mp = drop_mult1(KARG(TopBwdP, drop_p), (uint64_t)pe);
         }
         const float dp = dpd * mp;
         const float delta = group_sum<64>(p * dp);
@@ -406,20 +426,20 @@ top_bwd_kernel(const TopBwdP P) {
         gst(P.pbk + (long)b * 64 + c, sQ[c] * sSum[head]);
         gst(P.pbv + (long)b * 64 + c, sDC[c] * sSum[4 + head]);
     }
-    for (int o = tid; o < heads * 64; o += 256) {
-        const int head = o >> 6, i = o & 63;
+    if (hv) {
+        const int head = wave, i = lane, o = tid;
         float rk = 0.f, rv = 0.f;
         for (int j = 0; j < L; ++j) { const float x = sX[j * FS + i]; rk += sDs[head * 64 + j] * x; rv += sPd[head * 64 + j] * x; }
         const long e = ((long)b * heads + head) * 64 + i;
         const bool mine = i / DH == head;
         gst(P.rk + e, rk); gst(P.rv + e, rv);
         gst(P.ak + e, mine ? sQ[i] : 0.f); gst(P.av + e, mine ? sDC[i] : 0.f);
-        sQK[o] = gemv_cols<DH>(P.wk, 64, sQ, head * DH, i);
-        sCV[o] = gemv_cols<DH>(P.wv, 64, sDC, head * DH, i);
+        sQK[o] = gemv_cols_dot<DH>(wkc, sQ, head * DH);
+        sCV[o] = gemv_cols_dot<DH>(wvc, sDC, head * DH);
     }
     lds_barrier();
     // dq . Wq joins the last row's extra gradient (4 slices of 16 features)
-    sRed[wave * 64 + lane] = gemv_cols<16>(P.wq, 64, sDQ, 16 * wave, lane);
+    sRed[wave * 64 + lane] = gemv_cols_dot<16>(wqc, sDQ, 16 * wave);
     lds_barrier();
     if (tid < 64) sLast[tid] += (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
     lds_barrier();
