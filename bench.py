@@ -228,8 +228,10 @@ def main():
                       B * L * (24 * d * d + 8 * L * d + 16 * cb * d)),
                      (Lb.K_FUSED_FWD, "fused_layer_fwd_kernel (whole BSARecBlock forward per sequence)",
                       B * L * (24 * d * d + 4 * L * d + 8 * cb * d)),
-                     (Lb.K_DW1, "dw_direct_kernel (6 weight + bias gradients of a block, direct split-K; un-pruned FLOP count, "
-                                "the top block's launch reduces 4 of its 6 products over the last positions only)", 24.0 * T * d * d)]
+                     (Lb.K_DW1, "dw_direct_kernel (weight + bias gradients, direct split-K; un-pruned FLOP count of all N blocks over "
+                                "its N-1 launches: the top block's products use the one-row structure of their gradient and ride "
+                                "in the next block's launch)",
+                      24.0 * T * d * d * (N / max(N - 1, 1) if out["config"]["top_block"] != "full" else 1.0))]
         else:
             cands = [(Lb.K_FFN1, "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)", 2.0 * T * d * 4 * d),
                      (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d)]

@@ -24,6 +24,7 @@ static thread_local bool g_dry = false;
 
 static long long* g_stamps = nullptr;   // diagnostic stamp buffer (bsarec_debug_stamps)
 static int g_use_fused = 1;
+#define TOP_SLABS 4                 // slab slices of the pruned top block's weight-gradient products (K = B or B*h rows only)
 static int g_prune_top = 1;          // BSAREC_PRUNE_TOP=0: the loss path runs the full top block too
 static int g_use_direct_dw = 1;      // BSAREC_DW=tiled selects the LDS-tiled grouped kernel at the fused shape too      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
 
@@ -125,7 +126,8 @@ struct bsarec_plan {
     ReduceJob* jobs_pruned;                    // same table with the top layer's key / value bias jobs fed from partials
     bool prune_ok;                             // the loss path may run the pruned top block (fused shape, >= 2 layers)
     bool pruned;                               // mode of the last forward
-    float *part_kvb, *slab_dummy;              // [2][B][d] key / value bias partials of the pruned top block; [nsplit][4d] sink
+    float *part_kvb, *slab_dummy;
+    float *top_dq, *top_dO, *top_dT, *top_dU, *top_ak, *top_rk, *top_av, *top_rv;              // [2][B][d] key / value bias partials of the pruned top block; [nsplit][4d] sink
     int* blockmap; int red_blocks;           // flat block -> (job, chunk) table of the final gradient reduction
 };
 
@@ -220,6 +222,12 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     p.part_pos = cv.take<float>((long)p.pos_slices * L * d);
     p.trash = cv.take<float>(1024);
     p.part_kvb = cv.take<float>(2 * B * d);
+    // pruned top block: its last-row gradient operands and the rank-1 key / value operands live in their own compact
+    // buffers ([B][d], [B][4d], [B*h][d]) so that they survive the next block's backward and ride in ITS weight-gradient launch
+    p.top_dq = cv.take<float>(B * d); p.top_dO = cv.take<float>(B * d); p.top_dT = cv.take<float>(B * d);
+    p.top_dU = cv.take<float>(4 * B * d);
+    p.top_ak = cv.take<float>(B * h * d); p.top_rk = cv.take<float>(B * h * d);
+    p.top_av = cv.take<float>(B * h * d); p.top_rv = cv.take<float>(B * h * d);
     p.slab_dummy = cv.take<float>((long)p.nsplit * 4 * d);
     // guard pad: the direct weight-gradient kernel prefetches up to 40 token rows past a slice without predicates
     // (dw_direct.h); at the pruned top block those rows are L tokens apart
@@ -308,6 +316,8 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
         const size_t base = (size_t)(cfg->layers - 1) * 19;
         ReduceJob& jk = jobs_pr[base + 6]; jk.src = p->part_kvb; jk.nsplit = cfg->batch; jk.stride = d;
         ReduceJob& jv = jobs_pr[base + 8]; jv.src = p->part_kvb + (long)cfg->batch * d; jv.nsplit = cfg->batch; jv.stride = d;
+        for (int j : {3, 4, 5, 7, 9, 10, 13, 14, 15, 16})      // weights and the other biases: the pruned products fill TOP_SLABS slabs
+            jobs_pr[base + j].nsplit = std::min(TOP_SLABS, ns);
     }
     std::vector<int> bmap;
     for (size_t j = 0; j < jobs.size(); ++j)
@@ -543,8 +553,8 @@ static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStrea
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff; F.low = b.dsp;
     F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.vsplit; F.dh_stride = (long)c.batch * d;
-    F.dT = p.dT; F.dU = p.dU; F.dO = p.dO; F.dq = p.dq;
-    F.ak = p.dk; F.rk = p.dC; F.av = p.dv; F.rv = p.dF;
+    F.dT = p.top_dT; F.dU = p.top_dU; F.dO = p.top_dO; F.dq = p.top_dq;
+    F.ak = p.top_ak; F.rk = p.top_rk; F.av = p.top_av; F.rv = p.top_rv;
     F.pbk = p.part_kvb; F.pbv = p.part_kvb + (long)c.batch * d;
     F.pg_ff = p.part_ln + 0 * nb * d; F.pb_ff = p.part_ln + 1 * nb * d; F.pg_a = p.part_ln + 2 * nb * d;
     F.pb_a = p.part_ln + 3 * nb * d; F.pg_f = p.part_ln + 4 * nb * d; F.pb_f = p.part_ln + 5 * nb * d;
@@ -772,6 +782,9 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
         HIPCHK(hipGetLastError());
     }
 
+    DwP DW;                       // weight-gradient problems waiting for their launch (dw_direct.h)
+    memset(&DW, 0, sizeof(DW));
+    int dw_np = 0, dw_nu = 0;
     for (int l = N - 1; l >= 0; --l) {
         const bsarec_layer_t& w = p->P.layer[l];
         LayerBufs& b = p->lb[l];
@@ -890,14 +903,19 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                     g.A[0] += (long)(L - 1) * sp[i].lda; g.B[0] += (long)(L - 1) * sp[i].ldb;
                     g.lda *= L; g.ldb *= L;
                     g.kchunk = (int)rup(cdiv(B, ns), GEMM_BK);           // slices beyond ceil(B / kchunk) write zero slabs
+                    if (top_pruned) {                                    // gradient rows come compact ([B][M]) from top_bwd_kernel
+                        g.A[0] = i == 0 ? p->top_dq : i == 3 ? p->top_dO : i == 4 ? p->top_dU : p->top_dT;
+                        g.lda = sp[i].M;
+                        g.nsplit = std::min(TOP_SLABS, ns); g.kchunk = (int)rup(cdiv(B, g.nsplit), GEMM_BK);
+                    }
                 }
                 // pruned top block: dK, dV are rank-1 per (sequence, head) -> dWk = AK^T RK, dWv = AV^T RV over B*h rows
                 // (fused_top.h); their bias gradients come from per-sequence partials, the slab output is discarded
                 const bool compact = top_pruned && (i == 1 || i == 2);
                 if (compact) {
                     g = gemm_defaults(d, d, B * h);
-                    g.A[0] = i == 1 ? p->dk : p->dv; g.B[0] = i == 1 ? p->dC : p->dF; g.lda = d; g.ldb = d;
-                    g.nsplit = ns; g.kchunk = (int)rup(cdiv(B * h, ns), GEMM_BK);
+                    g.A[0] = i == 1 ? p->top_ak : p->top_av; g.B[0] = i == 1 ? p->top_rk : p->top_rv; g.lda = d; g.ldb = d;
+                    g.nsplit = std::min(TOP_SLABS, ns); g.kchunk = (int)rup(cdiv(B * h, g.nsplit), GEMM_BK);
                 }
                 G.P[i] = g;
                 G.E[i] = epi_linear<false, false, false>(slab_w_ptr(*p, sp[i].woff), sp[i].N);
@@ -910,22 +928,25 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
             }
             G.tile0[6] = tiles; G.nprob = 6;
             if (p->fused && g_use_direct_dw) {
-                // hidden = 64: direct split-K products, one workgroup per (problem, 64x64 tile, slab slice) -- dw_direct.h
-                DwP D;
-                memset(&D, 0, sizeof(D));
-                int nu = 0;
+                // hidden = 64: direct split-K products, one workgroup per (problem, 64x64 tile, slab slice) -- dw_direct.h.
+                // The pruned top block's six (tiny) problems are not launched on their own: they wait in DW and ride in
+                // the next block's launch.
                 for (int i = 0; i < 6; ++i) {
                     const GemmP& g = G.P[i];
-                    DwProblem& q = D.P[i];
+                    DwProblem& q = DW.P[dw_np];
                     q.A = g.A[0]; q.B = g.B[0]; q.lda = g.lda; q.ldb = g.ldb; q.M = g.M; q.N = g.N; q.K = g.K;
-                    q.kchunk = g.kchunk; q.slab = G.E[i].C[0]; q.bslab = G.bgrad[i]; q.gelu = G.b_gelu[i];
+                    q.kchunk = g.kchunk; q.nslab = g.nsplit; q.slab = G.E[i].C[0]; q.bslab = G.bgrad[i]; q.gelu = G.b_gelu[i];
                     for (int m0 = 0; m0 < q.M; m0 += 64)
-                        for (int n0 = 0; n0 < q.N; n0 += 64) D.U[nu++] = DwUnit{(short)i, (short)m0, (short)n0, 0};
+                        for (int n0 = 0; n0 < q.N; n0 += 64) DW.U[dw_nu++] = DwUnit{(short)dw_np, (short)m0, (short)n0, 0};
+                    ++dw_np;
                 }
-                D.nunits = nu; D.nslab = ns;
-                ProfScope prof(BSAREC_K_DW1, s);
-                LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * nu), dim3(256), 0, s, D);
-                HIPCHK(hipGetLastError());
+                if (!top_pruned) {
+                    DW.nunits = dw_nu; DW.nslab = ns;
+                    ProfScope prof(BSAREC_K_DW1, s);
+                    LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * dw_nu), dim3(256), 0, s, DW);
+                    HIPCHK(hipGetLastError());
+                    dw_np = 0; dw_nu = 0;
+                }
             } else {
             constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES;
             ProfScope prof(BSAREC_K_DW1, s);

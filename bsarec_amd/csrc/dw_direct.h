@@ -18,8 +18,8 @@
 #pragma once
 #include "fused_layer.h"
 
-#define DW_MAX_PROB 6
-#define DW_MAX_UNITS 16
+#define DW_MAX_PROB 12        // two blocks' worth: the pruned top block's problems ride in the next block's launch
+#define DW_MAX_UNITS 24
 #define DW_STAGES 5
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -30,6 +30,7 @@ struct DwProblem {
     const float* A; const float* B;     // gradient rows [K][M] (lda), activation rows [K][N] (ldb); M, N multiples of 64
     long lda, ldb;
     int M, N, K, kchunk;                // K tokens in total, kchunk per slab slice (multiple of 32)
+    int nslab;                          // slab slices of THIS problem (<= DwP::nslab; the tiny top-block problems use fewer)
     float* slab;                        // [nslab][M][N]
     float* bslab;                       // [nslab][M]
     int gelu;                           // erf-GELU on the activation operand while loading (dW2 = dT2^T . gelu(u))
@@ -118,6 +119,7 @@ dw_direct_kernel(const DwP G) {
     if (slab >= G.nslab) return;
     const DwUnit u = G.U[j % G.nunits];
     const DwProblem& Q = G.P[u.prob];
+    if (slab >= Q.nslab) return;
     const int m0 = u.m0, n0 = u.n0;
     // this wave's quarter of the slab slice
     const int sub = Q.kchunk >> 2;                                       // multiple of 8

@@ -260,7 +260,7 @@ struct TopBwdP {
     const float* tw;
     const float *xhat_f, *rstd_f, *q, *k, *v, *probs, *xhat_a, *rstd_a, *u, *xhat_ff, *rstd_ff, *low;
     const float* dh_slabs; int dh_nsplit; long dh_stride;   // dY of row L-1 = sum of the logits backward's split-K slabs [s][B][64]
-    float *dT, *dU, *dO, *dq;                                // last rows: operands of the last-position weight-gradient products
+    float *dT, *dU, *dO, *dq;                                // compact [B][64 | 256]: operands of the last-position weight-gradient products
     float *ak, *rk, *av, *rv;                                // [B * heads][64]: dWk = AK^T RK, dWv = AV^T RV
     float *pbk, *pbv;                                        // [B][64] key / value bias-gradient partials
     float *pg_ff, *pb_ff, *pg_a, *pb_a, *pg_f, *pb_f, *pbeta;   // [B][64] LayerNorm / sqrt_beta partials
@@ -335,7 +335,7 @@ top_bwd_kernel(const TopBwdP P) {
         gst(P.pb_ff + (long)b * 64 + c, dy);
         const float dt = dz_ff * drop_mult1(KARG(TopBwdP, drop_ff), (uint64_t)(el + c));
         sDT[c] = dt;
-        gst(P.dT + el + c, dt);
+        gst(P.dT + (long)b * 64 + c, dt);
     }
     lds_barrier();
 
@@ -343,7 +343,7 @@ top_bwd_kernel(const TopBwdP P) {
     {
         const float du = gemv_cols_dot<64>(w2c, sDT, 0) * gelu_grad_f(u_mine);
         sDU[tid] = du;
-        gst(P.dU + (tok0 + tl) * 256 + tid, du);
+        gst(P.dU + (long)b * 256 + tid, du);
     }
     lds_barrier();
     // ---- d(hmix) = dU . W1 + dz   (4 slices of 64 inner units)
@@ -368,7 +368,7 @@ top_bwd_kernel(const TopBwdP P) {
         const float dO = dza * drop_mult1(KARG(TopBwdP, drop_o), (uint64_t)(el + c));
         const float dF = dzf * drop_mult1(KARG(TopBwdP, drop_f), (uint64_t)(el + c));
         sDO[c] = dO;
-        gst(P.dO + el + c, dO);
+        gst(P.dO + (long)b * 64 + c, dO);
         const float bt = gld(P.sqrt_beta + c), b2 = bt * bt;
         sDF[c] = (1.0f - b2) * dF;
         sLast[c] = dza + dzf + b2 * dF;
@@ -422,7 +422,7 @@ top_bwd_kernel(const TopBwdP P) {
         float acc = 0.f;
         for (int j = 0; j < L; ++j) acc += sDs[head * 64 + j] * sK[j * FS + c];
         sDQ[c] = acc;
-        gst(P.dq + el + c, acc);
+        gst(P.dq + (long)b * 64 + c, acc);
         gst(P.pbk + (long)b * 64 + c, sQ[c] * sSum[head]);
         gst(P.pbv + (long)b * 64 + c, sDC[c] * sSum[4 + head]);
     }
