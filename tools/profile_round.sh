@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-graph --no-cpu-baseline > $OUT/trace_bench.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 200 --warmup 20 --no-graph --no-cpu-baseline --no-roofline > $OUT/trace_bench.log 2>&1
 echo trace done
 timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc/fetch -- python3 $R/tools/pmc_run.py 4 > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc/write -- python3 $R/tools/pmc_run.py 4 > $OUT/pmc_write.log 2>&1
