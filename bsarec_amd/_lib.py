@@ -5,7 +5,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSAREC_LIB") or os.path.join(HERE, "libbsarec_hip.so")   # BSAREC_LIB: another build of the same ABI
 MAX_LAYERS = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 (BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX,
  BUF_DLOGITS) = range(10)
@@ -67,7 +67,8 @@ EXPORTS = {
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_train_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 7 + [C.c_long] + [C.c_float] * 5 +
                                   [C.c_void_p]),
-    "bsarec_grad_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 4),
+    "bsarec_grad_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 3 + [C.c_float] * 3 + [C.c_void_p]),
+    "bsarec_adam_apply": (C.c_int, [C.c_void_p] * 4 + [C.c_long, C.c_void_p] + [C.c_float] * 5 + [C.c_void_p]),
     "bsarec_freq_layer_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_int,
                                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_freq_layer_bwd_scratch_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),

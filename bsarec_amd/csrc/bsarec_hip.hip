@@ -1026,6 +1026,12 @@ extern "C" int bsarec_adam_step(float* params, const float* grads, float* m, flo
     return adam_launch(params, grads, m, v, n, state, b1, b2, eps, wd, gscale, s);
 }
 
+extern "C" int bsarec_adam_apply(float* params, const float* grads, float* m, float* v, long n, void* state, float b1,
+                                 float b2, float eps, float wd, float gscale, void* stream) {
+    if (!params || !grads || !m || !v || !state || n <= 0 || (n & 3)) return -10;
+    return adam_launch(params, grads, m, v, n, state, b1, b2, eps, wd, gscale, (hipStream_t)stream);
+}
+
 extern "C" int bsarec_gather_batch(const int64_t* table, const int64_t* answers_table, const int64_t* perm, long n_samples,
                                    const void* cursor, int B, int L, int64_t* ids_out, int64_t* answers_out, void* stream) {
     if (!table || !answers_table || !perm || !cursor || !ids_out || !answers_out || B < 1 || L < 1) return -10;
@@ -1053,13 +1059,13 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
 
 extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, const int64_t* answers_table,
                                         const int64_t* perm, long n_samples, void* cursor, int64_t* ids_buf,
-                                        int64_t* answers_buf, void* stream) {
+                                        int64_t* answers_buf, float lr, float b1, float b2, void* stream) {
     if (!p || !table || !answers_table || !perm || !cursor || !ids_buf || !answers_buf) return -10;
     GatherP gp{table, answers_table, perm, n_samples, (const long long*)cursor, ids_buf, answers_buf};
     RET(forward_impl(p, ids_buf, 1, stream, gp, true));
     RET(bsarec_loss(p, answers_buf, stream));
     // same convention as bsarec_train_step_indexed: the step index / cursor advance when the step is done
-    return backward_impl(p, stream, make_tick(p->state, 0, 0.f, 0.f, 0.f, nullptr, 0, nullptr, cursor, p->cfg.batch, 1));
+    return backward_impl(p, stream, make_tick(p->state, lr > 0.f ? 1 : 0, lr, b1, b2, nullptr, 0, nullptr, cursor, p->cfg.batch, 1));
 }
 
 extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int64_t* answers, float* params_flat,

@@ -340,9 +340,10 @@ class BSARecModel(nn.Module):
             self._stream()), "bsarec_train_step_indexed")
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
-    def grad_step_indexed(self, table, answers_table, perm, cursor, batch: int) -> torch.Tensor:
+    def grad_step_indexed(self, table, answers_table, perm, cursor, batch: int, tick_adam: bool = False) -> torch.Tensor:
         """Data-parallel half of train_step_indexed: gather + forward + loss + backward into the gradient arena
-        (no Adam).  Follow with an all-reduce of ``_garena`` and :meth:`adam_step`."""
+        (no Adam).  Follow with an all-reduce of ``_garena`` and :meth:`adam_step` -- or, with ``tick_adam``, the step's
+        closing block already advances Adam's t / bias corrections and :meth:`adam_step(tick=False)` applies the update."""
         plan = self._plan(batch)
         if not hasattr(plan, "ids_buf"):
             dev = self._arena.device
@@ -350,12 +351,19 @@ class BSARecModel(nn.Module):
             plan.ans_buf = torch.zeros((batch,), dtype=torch.int64, device=dev)
         L.check(plan.lib.bsarec_grad_step_indexed(
             plan.handle, table.data_ptr(), answers_table.data_ptr(), perm.data_ptr(), perm.shape[0], cursor.data_ptr(),
-            plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), self._stream()), "bsarec_grad_step_indexed")
+            plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), self._adam["lr"] if tick_adam else 0.0,
+            self._adam["b1"] if tick_adam else 0.0, self._adam["b2"] if tick_adam else 0.0, self._stream()),
+            "bsarec_grad_step_indexed")
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
-    def adam_step(self, grad_scale: float = 1.0):
+    def adam_step(self, grad_scale: float = 1.0, tick: bool = True):
         """Fused Adam over the flat arenas (after an external gradient all-reduce)."""
         a = self._adam
+        if not tick:
+            L.check(L.load().bsarec_adam_apply(self._arena.data_ptr(), self._garena.data_ptr(), a["m"].data_ptr(),
+                                               a["v"].data_ptr(), self._numel, self._state.data_ptr(), a["b1"], a["b2"],
+                                               a["eps"], a["wd"], float(grad_scale), self._stream()), "bsarec_adam_apply")
+            return
         L.check(L.load().bsarec_adam_step(self._arena.data_ptr(), self._garena.data_ptr(), a["m"].data_ptr(),
                                           a["v"].data_ptr(), self._numel, self._state.data_ptr(), a["lr"], a["b1"],
                                           a["b2"], a["eps"], a["wd"], float(grad_scale), self._stream()),

@@ -148,13 +148,13 @@ class Trainer:
             if not self.dp:
                 loss = m.train_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B)
             else:
-                loss = m.grad_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B)
+                loss = m.grad_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B, tick_adam=True)
             if loss_sum is not None:
                 loss_sum.add_(loss)
             return loss
 
         def adam_part():
-            m.adam_step(grad_scale=1.0 / self.world)
+            m.adam_step(grad_scale=1.0 / self.world, tick=False)      # t / bias corrections: advanced by the grad step
 
         def exchange():
             allreduce_sum_(m._garena, self.pg, force=True)

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define BSAREC_MAX_LAYERS 16
-#define BSAREC_ABI_VERSION 1
+#define BSAREC_ABI_VERSION 2
 
 /* Hyper-parameters the reference model reads from `args`
  * (src/utils.py:83-96; src/model/bsarec.py:71-88; src/model/_modules.py:79-87). */
@@ -155,10 +155,16 @@ int bsarec_train_step_indexed(bsarec_plan_t *plan, const int64_t *table, const i
                               float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
 
 /* The data-parallel half of the above: gather + forward + loss + backward (no Adam).  The caller then all-reduces the
- * flat gradient arena (RCCL) and calls bsarec_adam_step(grad_scale = 1/world). */
+ * flat gradient arena (RCCL) and calls bsarec_adam_step(grad_scale = 1/world) -- or, when lr > 0 is given here, the
+ * step's closing block also advances Adam's t and publishes the bias corrections, and the caller follows the
+ * all-reduce with bsarec_adam_apply (one launch fewer per step).  lr <= 0: no Adam bookkeeping here. */
 int bsarec_grad_step_indexed(bsarec_plan_t *plan, const int64_t *table, const int64_t *answers_table,
                              const int64_t *perm, long n_samples, void *cursor, int64_t *ids_buf, int64_t *answers_buf,
-                             void *stream);
+                             float lr, float beta1, float beta2, void *stream);
+/* The parameter update of bsarec_adam_step alone (t and the bias corrections were already advanced by
+ * bsarec_grad_step_indexed(lr > 0)). */
+int bsarec_adam_apply(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, void *state,
+                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, void *stream);
 
 /* Stand-alone FrequencyLayer (src/model/bsarec.py:90-104) for per-op parity tests:
  * y = LN(Drop(low + beta^2 (x - low)) + x); backward given dy. */
