@@ -57,6 +57,7 @@ EXPORTS = {
     "bsarec_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bsarec_forward_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bsarec_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_loss_bce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_logits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_float,

@@ -126,6 +126,8 @@ struct bsarec_plan {
     ReduceJob* jobs_pruned;                    // same table with the top layer's key / value bias jobs fed from partials
     bool prune_ok;                             // the loss path may run the pruned top block (fused shape, >= 2 layers)
     bool pruned;                               // mode of the last forward
+    int loss_kind;                             // head of the last loss call: 0 = full-catalogue CE, 1 = SASRec's BCE pair
+    const int64_t *bce_pos, *bce_neg;
     float *part_kvb, *slab_dummy;
     float *top_dq, *top_dO, *top_dT, *top_dU, *top_ak, *top_rk, *top_av, *top_rv;              // [2][B][d] key / value bias partials of the pruned top block; [nsplit][4d] sink
     int* blockmap; int red_blocks;           // flat block -> (job, chunk) table of the final gradient reduction
@@ -311,6 +313,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     p->jobs_per_layer = 19;
     p->prune_ok = p->fused && cfg->layers >= 2 && g_prune_top;
     p->pruned = false;
+    p->loss_kind = 0; p->bce_pos = nullptr; p->bce_neg = nullptr;
     std::vector<ReduceJob> jobs_pr = jobs;          // key_b is job 6, value_b job 8 of a layer's 19 (state_dict order)
     {
         const size_t base = (size_t)(cfg->layers - 1) * 19;
@@ -483,7 +486,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.a_g = w.attn_ln_w; F.w1 = w.ffn1_w; F.w2 = w.ffn2_w; F.ff_g = w.ffn_ln_w; F.tw = p.twiddle;
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
-    if (top) { F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.vsplit; F.dh_stride = (long)c.batch * d; }
+    if (top) { F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.loss_kind == 1 ? 1 : p.vsplit; F.dh_stride = (long)c.batch * d; }
     if (l == 0) {       // the embedding front-end's backward (Drop + LayerNorm) rides in the bottom block's epilogue
         F.e_dz = p.dz; F.e_xhat = p.xhat0; F.e_rstd = p.rstd0; F.e_g = p.P.ln_w;
         F.e_pg = p.part_ln0; F.e_pb = p.part_ln0 + nb * d; F.e_drop = make_drop(p, c.p_hidden, 0, tr);
@@ -552,7 +555,7 @@ static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStrea
     F.a_g = w.attn_ln_w; F.w1 = w.ffn1_w; F.w2 = w.ffn2_w; F.ff_g = w.ffn_ln_w; F.tw = p.twiddle;
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff; F.low = b.dsp;
-    F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.vsplit; F.dh_stride = (long)c.batch * d;
+    F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.loss_kind == 1 ? 1 : p.vsplit; F.dh_stride = (long)c.batch * d;
     F.dT = p.top_dT; F.dU = p.top_dU; F.dO = p.top_dO; F.dq = p.top_dq;
     F.ak = p.top_ak; F.rk = p.top_rk; F.av = p.top_av; F.rv = p.top_rv;
     F.pbk = p.part_kvb; F.pbv = p.part_kvb + (long)c.batch * d;
@@ -717,6 +720,7 @@ static int loss_impl(bsarec_plan_t* p, const int64_t* answers, void* stream, boo
     if (!p || !answers) return -10;
     hipStream_t s = (hipStream_t)stream;
     RET(bsarec_logits(p, stream));
+    p->loss_kind = 0;
     const bsarec_config_t& c = p->cfg;
     LAUNCH(ce_rows_kernel, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, c.item_size, p->Vp,
                        1.0f / (float)c.batch, p->dlogits, p->loss_rows);
@@ -726,6 +730,18 @@ static int loss_impl(bsarec_plan_t* p, const int64_t* answers, void* stream, boo
 }
 
 extern "C" int bsarec_loss(bsarec_plan_t* p, const int64_t* answers, void* stream) { return loss_impl(p, answers, stream, true); }
+
+// SASRec's head (sibling model on the same encoder; run the plan with alpha = 0): src/model/sasrec.py:41-63
+extern "C" int bsarec_loss_bce(bsarec_plan_t* p, const int64_t* pos_ids, const int64_t* neg_ids, void* stream) {
+    if (!p || !pos_ids || !neg_ids) return -10;
+    hipStream_t s = (hipStream_t)stream;
+    const bsarec_config_t& c = p->cfg;
+    const int L = c.seq_len, d = c.hidden;
+    p->loss_kind = 1; p->bce_pos = pos_ids; p->bce_neg = neg_ids;
+    LAUNCH(bce_rows_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->X[c.layers] + (long)(L - 1) * d, (long)L * d, p->P.item_emb,
+           pos_ids, neg_ids, c.batch, d, c.item_size, p->dlogits, p->loss);
+    return (int)hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------
 // backward
@@ -750,6 +766,12 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
     const int ns = p->nsplit, nb = p->nblk;
     const float* hlast = p->X[N] + (long)(L - 1) * d;
 
+    if (p->loss_kind == 1) {     // SASRec's BCE pair: two embedding rows per sequence instead of the dense logits path
+        if (!g_dry) HIPCHK(hipMemsetAsync(p->G.item_emb, 0, (size_t)c.item_size * d * sizeof(float), s));
+        LAUNCH(bce_bwd_kernel, dim3(B), dim3(64), 0, s, hlast, (long)L * d, p->P.item_emb, p->bce_pos, p->bce_neg, p->dlogits, B, d,
+               c.item_size, p->dlast_slab, p->G.item_emb);
+        HIPCHK(hipGetLastError());
+    } else
     // dE (dense, logits path) = dlogits^T . h_last  [V, d] (overwrites the gradient buffer) and the split-K slabs of
     // d(h_last) = dlogits . E -- one launch
     {
@@ -778,7 +800,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
     float* dY = (N & 1) ? p->dXb : p->dXa;       // gradient w.r.t. X[l+1]; ping-pong so that dX[0] lands in dXa
     if (!p->fused) {      // the fused top-layer backward synthesises this gradient from the slabs itself
         LAUNCH(dlast_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, p->dlast_slab,
-               p->vsplit, (long)B * d, T, L, d, dY);
+               p->loss_kind == 1 ? 1 : p->vsplit, (long)B * d, T, L, d, dY);
         HIPCHK(hipGetLastError());
     }
 

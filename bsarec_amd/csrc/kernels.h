@@ -650,3 +650,61 @@ loss_mean_kernel(const float* __restrict__ rows, int B, float* __restrict__ out)
     }
     if (threadIdx.x == 0) out[0] = red[0] / (float)B;
 }
+
+// =============================================================================================
+// Sibling model SASRec: BCE head on one positive and one negative item at the last position
+// (src/model/sasrec.py:41-63).  loss = mean_{pos != 0} softplus(-x_pos) + mean_{pos != 0} softplus(x_neg),
+// x = <h_last, E[item]>.  One workgroup: per-row logits, the count of kept rows, the loss and the per-row
+// gradient coefficients coef[0][b] = d loss / d x_pos, coef[1][b] = d loss / d x_neg.
+// =============================================================================================
+__global__ void __launch_bounds__(ROW_THREADS)
+bce_rows_kernel(const float* __restrict__ hlast, long hstride, const float* __restrict__ E, const int64_t* __restrict__ pos,
+                const int64_t* __restrict__ neg, int B, int d, int V, float* __restrict__ coef, float* __restrict__ loss_out) {
+    __shared__ float red[2][ROW_THREADS];
+    float lsum = 0.f, cnt = 0.f;
+    for (int b = threadIdx.x; b < B; b += ROW_THREADS) {
+        int ip = (int)pos[b], in = (int)neg[b];
+        const bool keep = ip != 0;
+        ip = ip < 0 ? 0 : (ip >= V ? V - 1 : ip); in = in < 0 ? 0 : (in >= V ? V - 1 : in);
+        const float* h = hlast + (long)b * hstride;
+        float xp = 0.f, xn = 0.f;
+        for (int c = 0; c < d; c += 4) {
+            const f32x4 hv = ld4(h + c), ep = ld4(E + (long)ip * d + c), en = ld4(E + (long)in * d + c);
+            xp += hv.x * ep.x + hv.y * ep.y + hv.z * ep.z + hv.w * ep.w;
+            xn += hv.x * en.x + hv.y * en.y + hv.z * en.z + hv.w * en.w;
+        }
+        // softplus(z) = max(z, 0) + log1p(exp(-|z|))
+        const float sp = fmaxf(-xp, 0.f) + log1pf(expf(-fabsf(xp))), sn = fmaxf(xn, 0.f) + log1pf(expf(-fabsf(xn)));
+        if (keep) { lsum += sp + sn; cnt += 1.f; }
+        coef[b] = keep ? -1.0f / (1.0f + expf(xp)) : 0.f;            // -sigmoid(-xp)
+        coef[B + b] = keep ? 1.0f / (1.0f + expf(-xn)) : 0.f;         //  sigmoid(xn)
+    }
+    red[0][threadIdx.x] = lsum; red[1][threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = ROW_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    const float n = fmaxf(red[1][0], 1.f);
+    if (threadIdx.x == 0) loss_out[0] = red[0][0] / n;
+    for (int b = threadIdx.x; b < 2 * B; b += ROW_THREADS) coef[b] /= n;
+}
+
+// backward of the head: d(h_last)[b] = gp E[pos] + gn E[neg] -> slab 0 of the split-K layout the block backward
+// reads; dE[pos] += gp h_last, dE[neg] += gn h_last (dE zeroed by the caller; float atomics, one row per wave)
+__global__ void __launch_bounds__(64)
+bce_bwd_kernel(const float* __restrict__ hlast, long hstride, const float* __restrict__ E, const int64_t* __restrict__ pos,
+               const int64_t* __restrict__ neg, const float* __restrict__ coef, int B, int d, int V, float* __restrict__ dh,
+               float* __restrict__ dE) {
+    const int b = blockIdx.x;
+    int ip = (int)pos[b], in = (int)neg[b];
+    ip = ip < 0 ? 0 : (ip >= V ? V - 1 : ip); in = in < 0 ? 0 : (in >= V ? V - 1 : in);
+    const float gp = coef[b], gn = coef[B + b];
+    for (int c = threadIdx.x; c < d; c += 64) {
+        const float h = hlast[(long)b * hstride + c];
+        dh[(long)b * d + c] = gp * E[(long)ip * d + c] + gn * E[(long)in * d + c];
+        if (gp != 0.f) unsafeAtomicAdd(dE + (long)ip * d + c, gp * h);
+        if (gn != 0.f) unsafeAtomicAdd(dE + (long)in * d + c, gn * h);
+    }
+}
+

@@ -373,4 +373,91 @@ class BSARecModel(nn.Module):
         return OrderedDict((k, self._garena[o:o + n].view(shp)) for k, (o, n, shp) in self._slices.items())
 
 
-MODEL_DICT = {"bsarec": BSARecModel}       # src/model/__init__.py:10-19 (the one entry on the hot path)
+class _BCEFn(torch.autograd.Function):
+    """SASRec's loss head as one autograd node (bsarec_forward_last + bsarec_loss_bce; backward: bsarec_backward)."""
+
+    @staticmethod
+    def forward(ctx, model, ids, pos, neg, *params):
+        plan = model._run_forward(ids, train=model.training, new_step=model.training, last_only=True)
+        model._run_loss_bce(plan, pos, neg)
+        ctx.model, ctx.plan = model, plan
+        return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, plan = ctx.model, ctx.plan
+        model._run_backward(plan)
+        g = model._garena * gout
+        return (None, None, None, None) + tuple(g[o:o + n].view(shp) for (o, n, shp) in model._slices.values())
+
+
+class SASRecModel(BSARecModel):
+    """Sibling model on the same kernels: ``MODEL_DICT['sasrec'](args=args)``, src/model/sasrec.py.
+
+    The reference's TransformerBlock (src/model/_modules.py:142-151) is a BSARecBlock with alpha = 0 -- the mix
+    ``alpha * dsp + (1 - alpha) * gsp`` returns the attention branch -- so the encoder runs the BSARec plan with
+    alpha = 0; the frequency-layer tensors exist in the arena but receive exactly zero gradient and are neither
+    saved nor loaded.  What differs is the loss head (one positive / one negative logit, BCE, sasrec.py:41-63) and the
+    state_dict key names (``...blocks.{l}.layer.query.weight`` instead of ``...layer.attention_layer.query.weight``;
+    36 keys)."""
+
+    def __init__(self, args):
+        import copy
+        a = copy.copy(args)
+        a.alpha = 0.0
+        if not hasattr(a, "c"):
+            a.c = 3
+        super().__init__(a)
+
+    @staticmethod
+    def _ref_key(k: str):
+        if ".filter_layer." in k:
+            return None
+        return k.replace(".layer.attention_layer.", ".layer.")
+
+    def state_dict(self, *a, **kw):
+        sd = super().state_dict(*a, **kw)
+        return OrderedDict((self._ref_key(k), v) for k, v in sd.items() if self._ref_key(k) is not None)
+
+    def load_state_dict(self, state_dict, strict=True):
+        own = super().state_dict()
+        full = OrderedDict((k, v) for k, v in own.items())            # frequency-layer tensors keep their values
+        for k, v in state_dict.items():
+            kk = k.replace(".layer.", ".layer.attention_layer.") if (".layer." in k and ".attention_layer." not in k) else k
+            if kk not in own:
+                if strict:
+                    raise KeyError(f"unexpected key {k}")
+                continue
+            full[kk] = v
+        return super().load_state_dict(full, strict=strict)
+
+    def _run_loss_bce(self, plan, pos, neg):
+        dev = self._arena.device
+        p_ = pos.to(device=dev, dtype=torch.int64).contiguous()
+        n_ = neg.to(device=dev, dtype=torch.int64).contiguous()
+        L.check(plan.lib.bsarec_loss_bce(plan.handle, p_.data_ptr(), n_.data_ptr(), self._stream()), "bsarec_loss_bce")
+        plan._bce_keepalive = (p_, n_)
+
+    def calculate_loss(self, input_ids, answers, neg_answers=None, same_target=None, user_ids=None):
+        """src/model/sasrec.py:41-63: 0-d loss tensor; ``.backward()`` fills every parameter's grad."""
+        if neg_answers is None:
+            raise ValueError("SASRec's loss needs neg_answers (src/dataset.py:67)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _BCEFn.apply(self, input_ids, answers, neg_answers, *self.parameters())
+        plan = self._run_forward(input_ids, train=self.training, new_step=self.training, last_only=True)
+        self._run_loss_bce(plan, answers, neg_answers)
+        return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
+
+    def train_step(self, input_ids, answers, neg_answers=None) -> torch.Tensor:
+        """step_begin + forward + BCE head + backward + fused Adam, all on the device (five C calls)."""
+        if self._adam is None:
+            raise RuntimeError("call configure_adam() first")
+        plan = self._run_forward(input_ids, train=True, new_step=True, last_only=True)
+        self._run_loss_bce(plan, answers, neg_answers)
+        self._run_backward(plan)
+        self.adam_step()
+        return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
+
+# src/model/__init__.py:10-19: the hot-path entry and its first sibling on the same kernels
+MODEL_DICT = {"bsarec": BSARecModel, "sasrec": SASRecModel}

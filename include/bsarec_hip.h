@@ -120,6 +120,12 @@ int bsarec_loss(bsarec_plan_t *plan, const int64_t *answers, void *stream);
  * left unspecified.  BSAREC_PRUNE_TOP=0 makes this identical to bsarec_forward. */
 int bsarec_forward_last(bsarec_plan_t *plan, const int64_t *ids, int train, void *stream);
 
+/* Sibling model SASRec (src/model/sasrec.py:41-63): the BCE head on one positive and one negative item at the last
+ * position, over the rows with pos_ids != 0, instead of the full-catalogue CE.  Run it on a plan created with
+ * alpha = 0 (then a BSARecBlock is exactly the reference's TransformerBlock, src/model/_modules.py:142-151).  Loss ->
+ * BSAREC_BUF_LOSS; bsarec_backward then back-propagates this head (pos_ids / neg_ids must stay valid until then). */
+int bsarec_loss_bce(bsarec_plan_t *plan, const int64_t *pos_ids, const int64_t *neg_ids, void *stream);
+
 /* logits only (Trainer.predict_full, src/trainers.py:62-68). */
 int bsarec_logits(bsarec_plan_t *plan, void *stream);
 

@@ -345,8 +345,31 @@ def logits_and_loss(h_last, E, answers):
     return logits, nll.mean(dtype=np.float64), lse
 
 
+def bce_head(pos_ids, neg_ids):
+    """SASRecModel.calculate_loss's head (src/model/sasrec.py:41-63): one positive / one negative logit at the last
+    position, BCEWithLogits over the rows with pos_ids != 0 (both terms averaged over those rows)."""
+    def head(h_last, E, dtype):
+        t = dtype
+        pos_ids_, neg_ids_ = np.asarray(pos_ids), np.asarray(neg_ids)
+        keep = pos_ids_ != 0
+        n = max(int(keep.sum()), 1)
+        xp = (E[pos_ids_] * h_last).sum(-1).astype(np.float64)
+        xn = (E[neg_ids_] * h_last).sum(-1).astype(np.float64)
+        softplus = lambda z: np.maximum(z, 0) + np.log1p(np.exp(-np.abs(z)))
+        loss = (softplus(-xp)[keep].sum() + softplus(xn)[keep].sum()) / n
+        gp = np.where(keep, -1.0 / (1.0 + np.exp(xp)), 0.0) / n          # d loss / d xp = -sigmoid(-xp) / n
+        gn = np.where(keep, 1.0 / (1.0 + np.exp(-xn)), 0.0) / n          # d loss / d xn = sigmoid(xn) / n
+        gp, gn = gp.astype(t), gn.astype(t)
+        dE = np.zeros_like(E)
+        np.add.at(dE, pos_ids_, gp[:, None] * h_last)
+        np.add.at(dE, neg_ids_, gn[:, None] * h_last)
+        dh = gp[:, None] * E[pos_ids_] + gn[:, None] * E[neg_ids_]
+        return float(loss), None, dE, dh.astype(t)
+    return head
+
+
 def loss_and_grads(params, cfg: Config, ids, answers, drop: Optional[DropoutSpec] = None,
-                   dtype=np.float32, d_outs: Optional[List[np.ndarray]] = None):
+                   dtype=np.float32, d_outs: Optional[List[np.ndarray]] = None, head=None):
     """BSARecModel.calculate_loss + autograd backward (src/model/bsarec.py:30-37,
     src/trainers.py:103-106), derived by hand.  Returns
     (loss, logits, grads, layer_outputs).  ``d_outs`` optionally adds upstream gradients on the
@@ -365,13 +388,18 @@ def loss_and_grads(params, cfg: Config, ids, answers, drop: Optional[DropoutSpec
     G: Dict[str, np.ndarray] = {k: np.zeros_like(v) for k, v in P.items()}
 
     h_last = outs[-1][:, -1, :]
-    logits, loss, lse = logits_and_loss(h_last, E, answers)
-    dlog = np.exp(logits - lse[:, None])
-    dlog[np.arange(B), answers] -= 1
-    dlog = (dlog / t(B)).astype(dtype)
-    G["item_embeddings.weight"] += dlog.T @ h_last                  # dense dE incl. row 0 (A.8)
     dx = np.zeros_like(outs[-1])
-    dx[:, -1, :] = dlog @ E
+    if head is None:
+        logits, loss, lse = logits_and_loss(h_last, E, answers)
+        dlog = np.exp(logits - lse[:, None])
+        dlog[np.arange(B), answers] -= 1
+        dlog = (dlog / t(B)).astype(dtype)
+        G["item_embeddings.weight"] += dlog.T @ h_last                  # dense dE incl. row 0 (A.8)
+        dx[:, -1, :] = dlog @ E
+    else:                               # sibling models: another loss head on the same encoder (``answers`` unused)
+        loss, logits, dE_head, dh_head = head(h_last, E, dtype)
+        G["item_embeddings.weight"] += dE_head
+        dx[:, -1, :] = dh_head
     if d_outs is not None:
         dx = dx + d_outs[-1]
 

@@ -1,0 +1,116 @@
+"""Sibling model SASRec on the BSARec kernels: the oracle (alpha = 0 + BCE head) against golden vectors
+made by importing the reference's SASRecModel (tests/golden/make_golden_sasrec.py), and the HIP path against both."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_l2
+
+CASES = ["A_d64_L50_h2", "B_d64_L20_h4"]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, f"sasrec_{name}.npz"))
+    return z, json.loads(str(z["cfg"]))
+
+
+def to_bsarec_key(k):
+    return k.replace(".layer.", ".layer.attention_layer.") if ".layer." in k else k
+
+
+def oracle_setup(z, cfg):
+    from oracle import bsarec_oracle as O
+    c = O.Config(item_size=cfg["item_size"], hidden_size=cfg["hidden_size"], max_seq_length=cfg["max_seq_length"],
+                 num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"], c=3, alpha=0.0,
+                 hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    P = O.init_params(c, seed=1)                       # frequency-layer tensors: arbitrary, multiplied by alpha = 0
+    for k in z.files:
+        if k.startswith("p/"):
+            P[to_bsarec_key(k[2:])] = z[k]
+    return O, c, P
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_sasrec_vs_reference_golden(name):
+    z, cfg = load(name)
+    O, c, P = oracle_setup(z, cfg)
+    loss, _, G, outs = O.loss_and_grads(P, c, z["ids"], None, head=O.bce_head(z["pos"], z["neg"]))
+    assert abs(loss - float(z["loss"])) <= 2e-6 * abs(float(z["loss"]))
+    for i in range(cfg["num_hidden_layers"] + 1):
+        assert np.abs(outs[i] - z[f"out/{i}"]).max() <= 2e-5
+    for k in z.files:
+        if k.startswith("g/") and not k.endswith("key.bias"):
+            assert rel_l2(G[to_bsarec_key(k[2:])], z[k]) <= 2e-5, k
+    for k, g in G.items():                               # the unused frequency branch gets exactly nothing
+        if ".filter_layer." in k:
+            assert np.abs(g).max() == 0.0, k
+
+
+def test_sasrec_state_dict_contract():
+    torch = pytest.importorskip("torch")
+    from bsarec_amd import SASRecModel, MODEL_DICT
+    z, cfg = load(CASES[0])
+    a = argparse.Namespace(hidden_act="gelu", batch_size=8, alpha=0.7, c=5, **cfg)
+    m = MODEL_DICT["sasrec"](args=a)
+    assert isinstance(m, SASRecModel) and m.args.alpha == 0.0
+    keys = [k[2:] for k in z.files if k.startswith("p/")]
+    assert list(m.state_dict().keys()) == keys           # the reference's 4 + 16 N names, in its order
+    m.load_state_dict({k: torch.from_numpy(z["p/" + k]) for k in keys})
+    sd = m.state_dict()
+    for k in keys:
+        assert np.array_equal(sd[k].numpy(), z["p/" + k]), k
+    with pytest.raises(ValueError):
+        m.calculate_loss(torch.zeros(2, cfg["max_seq_length"], dtype=torch.long), torch.ones(2, dtype=torch.long))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prune", [1, 0])
+@pytest.mark.parametrize("name", CASES)
+def test_hip_sasrec_vs_reference_golden(name, prune):
+    """HIP path: layer outputs, BCE loss, all 36 gradients and three Adam steps against the imported reference."""
+    torch = pytest.importorskip("torch")
+    from bsarec_amd import SASRecModel, _lib as Lb
+    z, cfg = load(name)
+    Lb.load().bsarec_set_prune_top(prune)
+    try:
+        a = argparse.Namespace(hidden_act="gelu", batch_size=8, c=3, seed=1, **cfg)
+        m = SASRecModel(a)
+        keys = [k[2:] for k in z.files if k.startswith("p/")]
+        m.load_state_dict({k: torch.from_numpy(z["p/" + k]) for k in keys})
+        m = m.cuda()
+        m.train()
+        ids, pos, neg = (torch.from_numpy(z[k]).cuda() for k in ("ids", "pos", "neg"))
+        outs = m.forward(ids, all_sequence_output=True)
+        for i, o in enumerate(outs):
+            assert np.abs(o.cpu().numpy() - z[f"out/{i}"]).max() <= 2e-5, i
+        loss = m.calculate_loss(ids, pos, neg, None, None)
+        assert abs(loss.item() - float(z["loss"])) <= 2e-6 * abs(float(z["loss"]))
+        loss.backward()
+        G = m.grad_views()
+        for k in keys:
+            g = G[to_bsarec_key(k)].cpu().numpy()
+            if k.endswith("key.bias"):
+                assert np.abs(g).max() <= 1e-6
+                continue
+            assert rel_l2(g, z["g/" + k]) <= 1e-4, (k, rel_l2(g, z["g/" + k]))
+        for k, g in G.items():
+            if ".filter_layer." in k:
+                assert float(g.abs().max().item()) == 0.0, k
+        # three fused Adam steps
+        m.load_state_dict({k: torch.from_numpy(z["p/" + k]) for k in keys})
+        m.configure_adam(lr=1e-3)
+        losses = [m.train_step(ids, pos, neg).item() for _ in range(3)]
+        np.testing.assert_allclose(losses, z["adam_losses"], rtol=5e-6)
+        sd = m.state_dict()
+        for k in keys:
+            got, want = sd[k].cpu().numpy(), z["a/" + k]
+            if k.endswith("key.bias"):
+                assert np.abs(got - want).max() <= 3.5e-3
+                continue
+            bad = np.abs(got - want) > 2e-5
+            assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - want).max())
+    finally:
+        Lb.load().bsarec_set_prune_top(1)
