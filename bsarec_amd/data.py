@@ -113,6 +113,31 @@ class DeviceBatches:
         self.epoch = 0
         self.device = device
         self._empty = torch.zeros((0,), dtype=torch.int64, device=device)
+        self._neg_keys = None                      # enable_negatives(): sorted user * V + item membership keys
+
+    def enable_negatives(self, user_seq, item_size: int):
+        """Per-sample negative items as the reference draws them (src/dataset.py:67,120-124: a uniformly random item
+        id in [1, item_size) that the user never interacted with), on the device.  Needed by the sibling models with a
+        pairwise loss (SASRec); BSARec ignores neg_answer."""
+        keys = np.unique(np.concatenate([np.asarray(s, dtype=np.int64) + u * int(item_size) for u, s in enumerate(user_seq)]))
+        self._neg_keys = torch.as_tensor(keys, dtype=torch.int64, device=self.device)
+        self._neg_V = int(item_size)
+        self._neg_gen = torch.Generator(device=self.device)
+        self._neg_gen.manual_seed(self.seed + 7919)
+        return self
+
+    def sample_negatives(self, users: torch.Tensor) -> torch.Tensor:
+        V, keys = self._neg_V, self._neg_keys
+        neg = torch.randint(1, V, users.shape, device=self.device, generator=self._neg_gen)
+        for _ in range(64):                        # rejection loop (src/dataset.py:121-123)
+            k = users * V + neg
+            pos = torch.searchsorted(keys, k).clamp_(max=keys.shape[0] - 1)
+            bad = keys[pos] == k
+            nbad = int(bad.sum().item())
+            if nbad == 0:
+                break
+            neg[bad] = torch.randint(1, V, (nbad,), device=self.device, generator=self._neg_gen)
+        return neg
 
     def __len__(self):
         g = self.batch_size * self.world
@@ -151,5 +176,7 @@ class DeviceBatches:
             idx = perm[i * g:(i + 1) * g]
             if self.world > 1:
                 idx = shard_of_global_batch(idx, self.batch_size, self.rank, self.world)
-            yield (self.users[idx], self.inputs[idx], self.answers[idx], self._empty, self._empty.view(0))
+            users = self.users[idx]
+            neg = self.sample_negatives(users) if self._neg_keys is not None else self._empty
+            yield (users, self.inputs[idx], self.answers[idx], neg, self._empty.view(0))
         self.epoch += 1

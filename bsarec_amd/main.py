@@ -99,6 +99,8 @@ def run(args, user_seq, logger=None, checkpoint_path=None):
         indptr, cols = D.seen_csr(user_seq, split)
         setattr(args, f"{split}_rating_matrix", sp.csr_matrix((np.ones(len(cols)), cols, indptr), shape=(n_users, args.item_size)))
     model = MODEL_DICT[args.model_type.lower()](args=args)
+    if getattr(model, "needs_negatives", False):
+        train_dl.enable_negatives(user_seq, args.item_size)
     model.set_seed(args.seed)
     trainer = Trainer(model, train_dl, eval_dl, test_dl, args, logger)
     if args.do_eval:

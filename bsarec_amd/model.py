@@ -401,6 +401,8 @@ class SASRecModel(BSARecModel):
     state_dict key names (``...blocks.{l}.layer.query.weight`` instead of ``...layer.attention_layer.query.weight``;
     36 keys)."""
 
+    needs_negatives = True                       # Trainer: feed neg_answer (DeviceBatches.enable_negatives)
+
     def __init__(self, args):
         import copy
         a = copy.copy(args)

@@ -229,7 +229,8 @@ class Trainer:
         return self._loss_sum, nb
 
     def iteration(self, epoch, dataloader, train=True):
-        if train and isinstance(dataloader, DeviceBatches):
+        pairwise = getattr(self.model, "needs_negatives", False)       # sibling models with a pos / neg loss head (SASRec)
+        if train and isinstance(dataloader, DeviceBatches) and not pairwise:
             self.model.train()
             loss_sum, nb = self._epoch_indexed(dataloader)
             rec = loss_sum.item() / max(nb, 1)
@@ -247,8 +248,12 @@ class Trainer:
             nb = 0
             for batch in dataloader:
                 batch = tuple(t.to(self.device, non_blocking=True) for t in batch)
-                _, input_ids, answers, _, _ = batch
-                if self.use_graph and not self.dp:
+                _, input_ids, answers, neg_answers, _ = batch
+                if pairwise:
+                    if self.dp:
+                        raise NotImplementedError("data parallel is built for the BSARec step only")
+                    loss = self.model.train_step(input_ids, answers, neg_answers)
+                elif self.use_graph and not self.dp:
                     B = input_ids.shape[0]
                     first = B not in self._graphs
                     loss = self._step_graph(input_ids, answers)
