@@ -532,6 +532,7 @@ static int launch_top_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    F.stamps = g_stamps ? g_stamps + 32 * (2 * l) : nullptr;
     const size_t smem = top_fwd_smem_bytes();
 #define TOP_FWD_CASE(DHV) { \
         static bool attr = false; \
@@ -566,6 +567,7 @@ static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStrea
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha);
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
+    F.stamps = g_stamps ? g_stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = top_bwd_smem_bytes();
 #define TOP_BWD_CASE(DHV) { \
         static bool attr = false; \

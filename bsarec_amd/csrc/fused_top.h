@@ -22,12 +22,29 @@ struct TopFwdP {
     int L, Lp, cb, heads;
     float alpha, oma, eps;
     DropP drop_f, drop_p, drop_o, drop_ff;
+    long long* stamps;             // diagnostic: per-step shader clock of workgroup 0 (null in production)
 };
 
-__device__ __forceinline__ float drop_mult1(const DropP& d, uint64_t e) {
-    const f32x4 m = drop_mult4(d, e >> 2);
+// keep-mask x scale of ONE element (common.h: drop_mult4).  The Philox seed and step are read from the device state
+// once per kernel (DropSeed) -- drop_mult4 reads them at every call, a global round trip that in these single-row
+// chains would sit on the critical path behind whatever bulk prefetch was issued before it.
+struct DropSeed { uint32_t k0, k1, step; };
+__device__ __forceinline__ DropSeed drop_seed(const DropP& d) {
+    DropSeed s = {0u, 0u, 0u};
+    if (d.rng) {
+        const __attribute__((address_space(1))) uint64_t* rng = (const __attribute__((address_space(1))) uint64_t*)d.rng;
+        const uint64_t seed = rng[0];
+        s.k0 = (uint32_t)seed; s.k1 = (uint32_t)(seed >> 32); s.step = (uint32_t)rng[1];
+    }
+    return s;
+}
+__device__ __forceinline__ float drop_mult1(const DropP& d, const DropSeed& sd, uint64_t e) {
+    if (d.thresh == 0) return d.scale;
+    const uint64_t grp = e >> 2;
+    const uint4 w = philox4x32_10((uint32_t)grp, (uint32_t)(grp >> 32), d.site, sd.step, sd.k0, sd.k1);
     const int j = (int)(e & 3);
-    return j == 0 ? m.x : j == 1 ? m.y : j == 2 ? m.z : m.w;
+    const uint32_t r = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
+    return r >= d.thresh ? d.scale : 0.f;
 }
 
 // y[n] = sum_k W[n][k] x[k]  (nn.Linear forward, W row-major [*][ldw]); KS adjacent lanes share one output.
@@ -81,6 +98,7 @@ __device__ __forceinline__ void ln_row(float v, float eps, float& xhat, float& r
 template <int DH>
 __global__ void __launch_bounds__(256)
 top_fwd_kernel(const TopFwdP P) {
+#define PTYPE TopFwdP
     constexpr int TS = 64 * FS;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sX = sm;                       // x tile
@@ -96,10 +114,16 @@ top_fwd_kernel(const TopFwdP P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
+    STAMP(0);
     const int L = P.L, Lp = P.Lp, heads = P.heads, cb = P.cb;
     const int b = blockIdx.x, tl = L - 1;
     const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
 
+    // Loads return in issue order (vmcnt): the dropout seed and the small per-column vectors of the row steps go first
+    // so that no later step waits behind a bulk weight prefetch for them.
+    const DropSeed dseed = drop_seed(KARG(TopFwdP, drop_f));
+    const float c_beta = gld(P.sqrt_beta + lane), c_fg = gld(P.f_g + lane), c_fb = gld(P.f_b + lane), c_ag = gld(P.a_g + lane),
+                c_ab = gld(P.a_b + lane), c_ffg = gld(P.ff_g + lane), c_ffb = gld(P.ff_b + lane);
     // ---- load: x tile, ids, twiddles; K / V weight fragments for this wave's two 32 x 32 tiles
     const int wm = wave >> 1, wn = wave & 1, col = wn * 32 + l31;
     const long wrow = (long)col * 64 + 4 * half;
@@ -123,6 +147,7 @@ top_fwd_kernel(const TopFwdP P) {
     if (tid < 64) sIds[tid] = tid < L ? gldi(P.ids32 + (tok0 + tid)) : 0;
     build_twiddle_table(P.tw, L, cb, sTab);
     lds_barrier();
+    STAMP(1);
 
     // ---- K, V projections of all rows (MFMA), spectrum of x (VALU)
     {
@@ -139,9 +164,6 @@ top_fwd_kernel(const TopFwdP P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sV[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + bias_v;
     }
-    f32x4 w1r[16], w2r[16];
-    gemv_rows_load<64, 1>(P.w1, 64, tid, 0, w1r);
-    gemv_rows_load<256, 4>(P.w2, 256, on, osl, w2r);
     auto xsrc = [&](int, int t, int lc) { return ld4(sX + t * FS + lc); };
     dft_spectrum_tab<1>(xsrc, L, cb, sTab, sSpec, sPart);        // ends with a barrier: sK / sV complete too
 
@@ -162,16 +184,21 @@ top_fwd_kernel(const TopFwdP P) {
         const float low = (c & 3) == 0 ? low4.x : (c & 3) == 1 ? low4.y : (c & 3) == 2 ? low4.z : low4.w;
         const float xv = sX[tl * FS + c];
         gst(P.low + el + c, low);
-        const float bt = gld(P.sqrt_beta + c);
+        const float bt = c_beta;
         const float f = low + bt * bt * (xv - low);
-        const float v = f * drop_mult1(KARG(TopFwdP, drop_f), (uint64_t)(el + c)) + xv;
+        const float v = f * drop_mult1(KARG(TopFwdP, drop_f), dseed, (uint64_t)(el + c)) + xv;
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
         gst(P.xhat_f + el + c, xh);
         if (c == 0) gst(P.rstd_f + tok0 + tl, rs);
-        sDsp[c] = gld(P.f_g + c) * xh + gld(P.f_b + c);
+        sDsp[c] = c_fg * xh + c_fb;
     }
     lds_barrier();
+    STAMP(2);
+    // feed-forward weight rows: requested here (nothing below loads from global memory until they are used)
+    f32x4 w1r[16], w2r[16];
+    gemv_rows_load<64, 1>(P.w1, 64, tid, 0, w1r);
+    gemv_rows_load<256, 4>(P.w2, 256, on, osl, w2r);
 
     // ---- attention row of the last query: one wave per head, lane = key        src/model/_modules.py:118-135
     if (wave < heads) {
@@ -193,9 +220,10 @@ top_fwd_kernel(const TopFwdP P) {
         const float p = e / group_sum<64>(e);
         const long pe = (((long)b * heads + head) * L + tl) * Lp;
         if (key < Lp) gst(P.probs + pe + key, p);
-        sPd[head * 64 + key] = key < L ? p * drop_mult1(KARG(TopFwdP, drop_p), (uint64_t)(pe + key)) : 0.f;
+        sPd[head * 64 + key] = key < L ? p * drop_mult1(KARG(TopFwdP, drop_p), dseed, (uint64_t)(pe + key)) : 0.f;
     }
     lds_barrier();
+    STAMP(3);
     if (tid < 64) {                               // ctx_last[c] = sum_j Drop(p)_j v_j[c]
         const int c = tid, head = c / DH;
         float acc = 0.f;
@@ -204,6 +232,7 @@ top_fwd_kernel(const TopFwdP P) {
         gst(P.ctx + el + c, acc);
     }
     lds_barrier();
+    STAMP(4);
 
     // ---- dense + dropout + residual + LayerNorm + alpha mix (one row)
     {
@@ -211,19 +240,21 @@ top_fwd_kernel(const TopFwdP P) {
         if (osl == 0) sG[on] = o;
     }
     lds_barrier();
+    STAMP(5);
     if (wave == 0) {
         const int c = lane;
-        const float v = sG[c] * drop_mult1(KARG(TopFwdP, drop_o), (uint64_t)(el + c)) + sX[tl * FS + c];
+        const float v = sG[c] * drop_mult1(KARG(TopFwdP, drop_o), dseed, (uint64_t)(el + c)) + sX[tl * FS + c];
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
         gst(P.xhat_a + el + c, xh);
         if (c == 0) gst(P.rstd_a + tok0 + tl, rs);
-        const float a = gld(P.a_g + c) * xh + gld(P.a_b + c);
+        const float a = c_ag * xh + c_ab;
         const float hm = P.alpha * sDsp[c] + P.oma * a;
         sHm[c] = hm;
         gst(P.hmix + el + c, hm);
     }
     lds_barrier();
+    STAMP(6);
 
     // ---- feed-forward (one row): u = hmix W1^T + b1 (one output per thread), y = gelu(u) W2^T + b2
     {
@@ -232,21 +263,25 @@ top_fwd_kernel(const TopFwdP P) {
         sG[tid] = gelu_f(u);
     }
     lds_barrier();
+    STAMP(7);
     {
         const float y = gemv_rows_dot<256, 4>(w2r, sG, osl) + b2_n;
         if (osl == 0) sQ[on] = y;
     }
     lds_barrier();
+    STAMP(8);
     if (wave == 0) {
         const int c = lane;
-        const float v = sQ[c] * drop_mult1(KARG(TopFwdP, drop_ff), (uint64_t)(el + c)) + sHm[c];
+        const float v = sQ[c] * drop_mult1(KARG(TopFwdP, drop_ff), dseed, (uint64_t)(el + c)) + sHm[c];
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
         gst(P.xhat_ff + el + c, xh);
         if (c == 0) gst(P.rstd_ff + tok0 + tl, rs);
-        gst(P.Xout + el + c, gld(P.ff_g + c) * xh + gld(P.ff_b + c));
+        gst(P.Xout + el + c, c_ffg * xh + c_ffb);
     }
+    STAMP(15);
 }
+#undef PTYPE
 
 static inline size_t top_fwd_smem_bytes() { return (size_t)(3 * 64 * FS + 8192 + 2 * FUSED_MAX_CB * 128 + 768 + 64) * 4; }
 
@@ -267,6 +302,7 @@ struct TopBwdP {
     int L, Lp, cb, heads;
     float alpha, oma;
     DropP drop_f, drop_p, drop_o, drop_ff;
+    long long* stamps;
 };
 
 // LayerNorm backward of one row, one column per lane: returns dz; g = dy * gamma
@@ -280,6 +316,7 @@ __device__ __forceinline__ float ln_row_bwd(float dy, float gamma, float xhat, f
 template <int DH>
 __global__ void __launch_bounds__(256)
 top_bwd_kernel(const TopBwdP P) {
+#define PTYPE TopBwdP
     constexpr int TS = 64 * FS;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sX = sm;
@@ -305,39 +342,46 @@ top_bwd_kernel(const TopBwdP P) {
     float* sSum = sVec + 2112;    // [2][4] sum_j ds, sum_j Drop(p) per head
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    STAMP(0);
     const int L = P.L, Lp = P.Lp, heads = P.heads, cb = P.cb;
     const int b = blockIdx.x, tl = L - 1;
     const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
 
-    // ---- tiles and the upstream gradient
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
-        f32x4 x = {0, 0, 0, 0}, k = x, v = x;
-        if (r < L) { x = gld4(P.X + (tok0 + r) * 64 + c4); k = gld4(P.k + (tok0 + r) * 64 + c4); v = gld4(P.v + (tok0 + r) * 64 + c4); }
-        st4(sX + r * FS + c4, x); st4(sK + r * FS + c4, k); st4(sV + r * FS + c4, v);
-    }
+    // Loads return in issue order (vmcnt), so the order of issue is the order of need: the row vectors of the
+    // LayerNorm steps first, then the dense_2 columns of the first product; the x / k / v tiles (needed from the
+    // attention step on) and the dense_1 columns are requested after the first barrier and land during dU / dH.
+    const int c = lane;
+    const DropSeed dseed = drop_seed(KARG(TopBwdP, drop_f));
     build_twiddle_table(P.tw, L, cb, sTab);
-    // weight columns of the vector products, requested up front: dense_2 / dense_1 now, the small ones after the first step
-    float w2c[64], w1c[64];
-    gemv_cols_load<64>(P.w2, 256, 0, tid, w2c);
-    gemv_cols_load<64>(P.w1, 64, 64 * wave, lane, w1c);
+    float dy = 0.f;
+    for (int sp = 0; sp < P.dh_nsplit; ++sp) dy += gld(P.dh_slabs + sp * P.dh_stride + (long)b * 64 + c);
+    const float xh_ff = gld(P.xhat_ff + el + c), g_ff = gld(P.ff_g + c), rs_ff = gld(P.rstd_ff + tok0 + tl);
+    const float xa = gld(P.xhat_a + el + c), xf = gld(P.xhat_f + el + c), g_a = gld(P.a_g + c), g_f = gld(P.f_g + c);
+    const float rs_a = gld(P.rstd_a + tok0 + tl), rs_f = gld(P.rstd_f + tok0 + tl);
+    const float bt = gld(P.sqrt_beta + c), low_l = gld(P.low + el + c), x_l = gld(P.X + el + c);
     const float u_mine = gld(P.u + (tok0 + tl) * 256 + tid);
     if (tid < 64) sQ[tid] = gld(P.q + el + tid);
+    float w2c[64], w1c[64];
+    gemv_cols_load<64>(P.w2, 256, 0, tid, w2c);
     float dz_ff = 0.f;
     if (wave == 0) {            // FeedForward LayerNorm backward (row L-1)
-        const int c = lane;
-        float dy = 0.f;
-        for (int sp = 0; sp < P.dh_nsplit; ++sp) dy += gld(P.dh_slabs + sp * P.dh_stride + (long)b * 64 + c);
-        const float xh = gld(P.xhat_ff + el + c);
-        dz_ff = ln_row_bwd(dy, gld(P.ff_g + c), xh, gld(P.rstd_ff + tok0 + tl));
-        gst(P.pg_ff + (long)b * 64 + c, dy * xh);
+        dz_ff = ln_row_bwd(dy, g_ff, xh_ff, rs_ff);
+        gst(P.pg_ff + (long)b * 64 + c, dy * xh_ff);
         gst(P.pb_ff + (long)b * 64 + c, dy);
-        const float dt = dz_ff * drop_mult1(KARG(TopBwdP, drop_ff), (uint64_t)(el + c));
+        const float dt = dz_ff * drop_mult1(KARG(TopBwdP, drop_ff), dseed, (uint64_t)(el + c));
         sDT[c] = dt;
         gst(P.dT + (long)b * 64 + c, dt);
     }
     lds_barrier();
+    STAMP(1);
+    gemv_cols_load<64>(P.w1, 64, 64 * wave, lane, w1c);
+    f32x4 tx[4], tk[4], tv[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+        tx[p] = f32x4{0, 0, 0, 0}; tk[p] = tx[p]; tv[p] = tx[p];
+        if (r < L) { tx[p] = gld4(P.X + (tok0 + r) * 64 + c4); tk[p] = gld4(P.k + (tok0 + r) * 64 + c4); tv[p] = gld4(P.v + (tok0 + r) * 64 + c4); }
+    }
 
     // ---- dU = (dT2 . W2) * gelu'(u)   (one of the 256 inner units per thread)
     {
@@ -346,6 +390,7 @@ top_bwd_kernel(const TopBwdP P) {
         gst(P.dU + (long)b * 256 + tid, du);
     }
     lds_barrier();
+    STAMP(2);
     // ---- d(hmix) = dU . W1 + dz   (4 slices of 64 inner units)
     float woc[16], wqc[16], wkc[DH], wvc[DH];
     gemv_cols_load<16>(P.wo, 64, 16 * wave, lane, woc);
@@ -354,26 +399,30 @@ top_bwd_kernel(const TopBwdP P) {
     gemv_cols_load<DH>(P.wk, 64, (hv ? wave : 0) * DH, lane, wkc);
     gemv_cols_load<DH>(P.wv, 64, (hv ? wave : 0) * DH, lane, wvc);
     sRed[wave * 64 + lane] = gemv_cols_dot<64>(w1c, sDU, 64 * wave);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {                 // the tiles have landed by now
+        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+        st4(sX + r * FS + c4, tx[p]); st4(sK + r * FS + c4, tk[p]); st4(sV + r * FS + c4, tv[p]);
+    }
     lds_barrier();
+    STAMP(3);
     if (wave == 0) {
-        const int c = lane;
         const float dh = (sRed[c] + sRed[64 + c]) + (sRed[128 + c] + sRed[192 + c]) + dz_ff;
         // alpha mix + the two LayerNorm backwards (attention branch scaled by 1 - alpha, filter branch by alpha)
         const float dya = P.oma * dh, dyf = P.alpha * dh;
-        const float xa = gld(P.xhat_a + el + c), xf = gld(P.xhat_f + el + c);
-        const float dza = ln_row_bwd(dya, gld(P.a_g + c), xa, gld(P.rstd_a + tok0 + tl));
-        const float dzf = ln_row_bwd(dyf, gld(P.f_g + c), xf, gld(P.rstd_f + tok0 + tl));
+        const float dza = ln_row_bwd(dya, g_a, xa, rs_a);
+        const float dzf = ln_row_bwd(dyf, g_f, xf, rs_f);
         gst(P.pg_a + (long)b * 64 + c, dya * xa); gst(P.pb_a + (long)b * 64 + c, dya);
         gst(P.pg_f + (long)b * 64 + c, dyf * xf); gst(P.pb_f + (long)b * 64 + c, dyf);
-        const float dO = dza * drop_mult1(KARG(TopBwdP, drop_o), (uint64_t)(el + c));
-        const float dF = dzf * drop_mult1(KARG(TopBwdP, drop_f), (uint64_t)(el + c));
+        const float dO = dza * drop_mult1(KARG(TopBwdP, drop_o), dseed, (uint64_t)(el + c));
+        const float dF = dzf * drop_mult1(KARG(TopBwdP, drop_f), dseed, (uint64_t)(el + c));
         sDO[c] = dO;
         gst(P.dO + (long)b * 64 + c, dO);
-        const float bt = gld(P.sqrt_beta + c), b2 = bt * bt;
+        const float b2 = bt * bt;
         sDF[c] = (1.0f - b2) * dF;
         sLast[c] = dza + dzf + b2 * dF;
         // d sqrt_beta: f = low + beta^2 (x - low)
-        gst(P.pbeta + (long)b * 64 + c, 2.0f * bt * dF * (sX[tl * FS + c] - gld(P.low + el + c)));
+        gst(P.pbeta + (long)b * 64 + c, 2.0f * bt * dF * (x_l - low_l));
         // column L-1 of the low-pass projector: P[j][L-1] = (1/L) sum_k w_k cos(2 pi k (j - (L-1)) / L)
         float pl = 0.f;
         if (c < L)
@@ -384,11 +433,14 @@ top_bwd_kernel(const TopBwdP P) {
         sPl[c] = pl / (float)L;
     }
     lds_barrier();
+    STAMP(4);
     // ---- dC = dO . Wo   (4 slices of 16 output features)
     sRed[wave * 64 + lane] = gemv_cols_dot<16>(woc, sDO, 16 * wave);
     lds_barrier();
+    STAMP(5);
     if (tid < 64) sDC[tid] = (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
     lds_barrier();
+    STAMP(6);
 
     // ---- attention backward of the last query: one wave per head, lane = key
     if (wave < heads) {
@@ -404,7 +456,7 @@ top_bwd_kernel(const TopBwdP P) {
             }
             const long pe = (((long)b * heads + head) * L + tl) * Lp + key;
             p = gld(P.probs + pe);
-            mp = drop_mult1(KARG(TopBwdP, drop_p), (uint64_t)pe);
+            mp = drop_mult1(KARG(TopBwdP, drop_p), dseed, (uint64_t)pe);
         }
         const float dp = dpd * mp;
         const float delta = group_sum<64>(p * dp);
@@ -416,6 +468,7 @@ top_bwd_kernel(const TopBwdP P) {
         if (key == 0) { sSum[head] = s1; sSum[4 + head] = s2; }
     }
     lds_barrier();
+    STAMP(7);
     // ---- per-head vectors: dq, the weight-gradient operands of key / value, q_h Wk_h, dC_h Wv_h
     if (tid < 64) {
         const int c = tid, head = c / DH;
@@ -438,11 +491,14 @@ top_bwd_kernel(const TopBwdP P) {
         sCV[o] = gemv_cols_dot<DH>(wvc, sDC, head * DH);
     }
     lds_barrier();
+    STAMP(8);
     // dq . Wq joins the last row's extra gradient (4 slices of 16 features)
     sRed[wave * 64 + lane] = gemv_cols_dot<16>(wqc, sDQ, 16 * wave);
     lds_barrier();
+    STAMP(9);
     if (tid < 64) sLast[tid] += (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
     lds_barrier();
+    STAMP(10);
     // ---- dX, all rows
     {
         const int lr = tid >> 4, lc = (tid & 15) << 2;
@@ -455,6 +511,8 @@ top_bwd_kernel(const TopBwdP P) {
             gst4(P.dX + (tok0 + j) * 64 + lc, dx);
         }
     }
+    STAMP(15);
 }
+#undef PTYPE
 
 static inline size_t top_bwd_smem_bytes() { return (size_t)(3 * 64 * FS + FUSED_MAX_CB * 128 + 2176) * 4; }

@@ -18,7 +18,13 @@ lib.bsarec_debug_stamps(None)
 s = buf.cpu().numpy().reshape(4, 32)
 names = {0: ["load", "freq", "qkv", "attn", "dense+ln", "ffn1", "ffn2", "ln_ff"],
          1: ["ln_ff_bwd", "dU", "dH", "ln_a/f_bwd", "dC", "attn_bwd", "dXqkv", "freq_bwd"]}
-for l in range(2):
+for k in range(2):                      # the pruned top block (layer 1): raw stamp deltas per barrier step
+    row = s[2 + k]
+    n = 16
+    vals = [int(v) for v in row[:n]]
+    nz = [i for i, v in enumerate(vals) if v]
+    print(f"layer 1 {'top_bwd' if k else 'top_fwd'} stamps:", " ".join(f"{i}:{vals[i] - vals[nz[0]]}" for i in nz))
+for l in range(1):
     for k in range(2):
         row = s[2 * l + k]
         d = np.diff(row[:9])
