@@ -344,3 +344,16 @@ def test_train_from_scratch_lastfm_follows_the_reference_log():
     ref = z["metrics"]
     assert 0.6 * ref[2] <= scores[2] <= 1.4 * ref[2], (scores, ref)          # HR@10
     assert 0.7 * ref[3] <= scores[3] <= 1.3 * ref[3], (scores, ref)          # NDCG@10
+
+
+def test_tiled_weight_gradient_fallback_matches_too():
+    """BSAREC_DW=tiled (LDS-tiled grouped weight-gradient kernel at the fused shape, instead of the direct one) is a
+    process-wide switch read at plan creation, so it is exercised in a child process: the dropout-on oracle parity test
+    (loss + all gradients, pruned and full top block) must pass there as well."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BSAREC_DW="tiled")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
+                        "-k", "test_dropout_training_step_vs_oracle and A_d64"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout, r.stdout[-500:]

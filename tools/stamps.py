@@ -26,6 +26,8 @@ for k in range(2):                      # the pruned top block (layer 1): raw st
     print(f"layer 1 {'top_bwd' if k else 'top_fwd'} stamps:", " ".join(f"{i}:{vals[i] - vals[nz[0]]}" for i in nz))
 for l in range(1):
     for k in range(2):
-        row = s[2 * l + k]
+        row = s[2 * l + k].copy()
+        if k == 0:
+            row[2] = row[1]              # the forward has no stamp between the FrequencyLayer || QKV phases
         d = np.diff(row[:9])
         print(f"layer {l} {'bwd' if k else 'fwd'} total {row[8]-row[0]} cyc:", " ".join(f"{n}={int(x)}" for n, x in zip(names[k], d)))
