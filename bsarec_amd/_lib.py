@@ -5,7 +5,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSAREC_LIB") or os.path.join(HERE, "libbsarec_hip.so")   # BSAREC_LIB: another build of the same ABI
 MAX_LAYERS = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 (BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX,
  BUF_DLOGITS) = range(10)
@@ -27,6 +27,7 @@ LAYER_KEYS = {
     "ffn2_w": "feed_forward.dense_2.weight", "ffn2_b": "feed_forward.dense_2.bias",
     "ffn_ln_w": "feed_forward.LayerNorm.weight", "ffn_ln_b": "feed_forward.LayerNorm.bias",
 }
+OPTIONAL_LAYER_KEYS = {"filter_cw": "layer.filter_layer.complex_weight"}      # sibling model FMLPRec only
 TOP_KEYS = {"item_emb": "item_embeddings.weight", "pos_emb": "position_embeddings.weight",
             "ln_w": "LayerNorm.weight", "ln_b": "LayerNorm.bias"}
 
@@ -34,11 +35,11 @@ TOP_KEYS = {"item_emb": "item_embeddings.weight", "pos_emb": "position_embedding
 class Config(C.Structure):
     _fields_ = [("batch", C.c_int), ("seq_len", C.c_int), ("hidden", C.c_int), ("heads", C.c_int), ("layers", C.c_int),
                 ("item_size", C.c_int), ("cutoff_bins", C.c_int), ("alpha", C.c_float), ("ln_eps", C.c_float),
-                ("p_hidden", C.c_float), ("p_attn", C.c_float)]
+                ("p_hidden", C.c_float), ("p_attn", C.c_float), ("filter_kind", C.c_int)]
 
 
 class Layer(C.Structure):
-    _fields_ = [(f, C.c_void_p) for f in LAYER_FIELDS]
+    _fields_ = [(f, C.c_void_p) for f in LAYER_FIELDS] + [("filter_cw", C.c_void_p)]
 
 
 class Tensors(C.Structure):
@@ -58,6 +59,7 @@ EXPORTS = {
     "bsarec_forward_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "bsarec_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_loss_bce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_loss_logsig": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_logits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_float,

@@ -129,6 +129,7 @@ struct bsarec_plan {
     int loss_kind;                             // head of the last loss call: 0 = full-catalogue CE, 1 = SASRec's BCE pair
     const int64_t *bce_pos, *bce_neg;
     float *part_kvb, *slab_dummy;
+    float* part_cwL[BSAREC_MAX_LAYERS];        // FMLPRec: per-sequence d(complex_weight) [B][cb][d][2]
     float *top_dq, *top_dO, *top_dT, *top_dU, *top_ak, *top_rk, *top_av, *top_rv;              // [2][B][d] key / value bias partials of the pruned top block; [nsplit][4d] sink
     int* blockmap; int red_blocks;           // flat block -> (job, chunk) table of the final gradient reduction
 };
@@ -152,12 +153,15 @@ static int check_cfg(const bsarec_config_t& c) {
     if (c.cutoff_bins < 1 || c.cutoff_bins > c.seq_len / 2 + 1) return -6;
     if ((long)c.cutoff_bins * c.hidden > 8192) return -7;      // spectrum must fit the LDS carve
     if (c.p_hidden < 0.f || c.p_hidden >= 1.f || c.p_attn < 0.f || c.p_attn >= 1.f) return -8;
+    if (c.filter_kind != 0 && c.filter_kind != 1) return -9;
+    if (c.filter_kind == 1 && c.cutoff_bins != c.seq_len / 2 + 1) return -9;     // the learnable filter has every rFFT bin
     return 0;
 }
 
 static bool fused_shape_ok(const bsarec_config_t& c) {
     const int dh = c.hidden / c.heads;
-    return g_use_fused && c.hidden == 64 && c.seq_len <= 64 && c.cutoff_bins <= FUSED_MAX_CB && (dh == 16 || dh == 32 || dh == 64);
+    return g_use_fused && c.filter_kind == 0 && c.hidden == 64 && c.seq_len <= 64 && c.cutoff_bins <= FUSED_MAX_CB &&
+           (dh == 16 || dh == 32 || dh == 64);
 }
 
 static void derive(bsarec_plan& p) {
@@ -191,9 +195,10 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     const long T = p.T, d = c.hidden, B = c.batch, L = c.seq_len, h = c.heads, N = c.layers;
     const long Td = T * d;
     Carver cv(base);
-    p.jobs = cv.take<ReduceJob>((size_t)(N * 19 + 3));
-    p.jobs_pruned = cv.take<ReduceJob>((size_t)(N * 19 + 3));
-    p.blockmap = cv.take<int>((size_t)(N * (12 * cdiv(d * d, 64) + 16 * cdiv(4 * d, 64)) + cdiv(L * d, 64) + 2 * cdiv(d, 64) + 64));
+    p.jobs = cv.take<ReduceJob>((size_t)(N * 20 + 3));
+    p.jobs_pruned = cv.take<ReduceJob>((size_t)(N * 20 + 3));
+    p.blockmap = cv.take<int>((size_t)(N * (12 * cdiv(d * d, 64) + 16 * cdiv(4 * d, 64) + cdiv((long)c.cutoff_bins * d * 2, 64)) +
+                                       cdiv(L * d, 64) + 2 * cdiv(d, 64) + 64));
     p.ids32 = cv.take<int>(T);
     for (int l = 0; l <= N; ++l) p.X[l] = cv.take<float>(Td);
     p.xhat0 = cv.take<float>(Td); p.rstd0 = cv.take<float>(T);
@@ -224,6 +229,7 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     p.part_pos = cv.take<float>((long)p.pos_slices * L * d);
     p.trash = cv.take<float>(1024);
     p.part_kvb = cv.take<float>(2 * B * d);
+    for (int l = 0; l < N; ++l) p.part_cwL[l] = c.filter_kind == 1 ? cv.take<float>(B * c.cutoff_bins * d * 2) : nullptr;
     // pruned top block: its last-row gradient operands and the rank-1 key / value operands live in their own compact
     // buffers ([B][d], [B][4d], [B*h][d]) so that they survive the next block's backward and ride in ITS weight-gradient launch
     p.top_dq = cv.take<float>(B * d); p.top_dO = cv.take<float>(B * d); p.top_dT = cv.take<float>(B * d);
@@ -310,6 +316,9 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     add(p->part_ln0 + 0L * nb * d, p->G.ln_w, nb, d);
     add(p->part_ln0 + 1L * nb * d, p->G.ln_b, nb, d);
     add(p->part_pos, p->G.pos_emb, p->pos_slices, (long)cfg->seq_len * d);
+    if (cfg->filter_kind == 1)                 // FMLPRec: d(complex_weight) of every layer, summed over the sequences
+        for (int l = 0; l < cfg->layers; ++l)
+            add(p->part_cwL[l], p->G.layer[l].filter_cw, cfg->batch, (long)cfg->cutoff_bins * d * 2);
     p->jobs_per_layer = 19;
     p->prune_ok = p->fused && cfg->layers >= 2 && g_prune_top;
     p->pruned = false;
@@ -408,7 +417,8 @@ static size_t freq_smem(int L, int d, int cb, int nsrc) {
 
 template <int LPR>
 static int launch_freq_fwd(const float* X, const float* sb, const float* g, const float* be, float eps, DropP drop,
-                           const float* tw, int B, int L, int d, int cb, float* dsp, float* xhat, float* rstd, hipStream_t s) {
+                           const float* tw, int B, int L, int d, int cb, float* dsp, float* xhat, float* rstd, hipStream_t s,
+                           const float* cw = nullptr) {
     auto kern = freq_fwd_kernel<LPR>;
     const size_t smem = freq_smem(L, d, cb, 1);
     static size_t attr = 0;
@@ -416,13 +426,13 @@ static int launch_freq_fwd(const float* X, const float* sb, const float* g, cons
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = smem;
     }
-    LAUNCH(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, sb, g, be, eps, drop, tw, L, d, cb, dsp, xhat, rstd);
+    LAUNCH(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, sb, g, be, eps, drop, tw, L, d, cb, dsp, xhat, rstd, cw);
     return (int)hipGetLastError();
 }
 
 template <int LPR>
 static int launch_freq_bwd(const float* X, const float* dF, const float* dXin, const float* sb, const float* tw, int B, int L,
-                           int d, int cb, float* dX, float* pbeta, hipStream_t s) {
+                           int d, int cb, float* dX, float* pbeta, hipStream_t s, const float* cw = nullptr, float* pcw = nullptr) {
     auto kern = freq_bwd_kernel<LPR>;
     const size_t smem = freq_smem(L, d, cb, 2);
     static size_t attr = 0;
@@ -430,7 +440,7 @@ static int launch_freq_bwd(const float* X, const float* dF, const float* dXin, c
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = smem;
     }
-    LAUNCH(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, dF, dXin, sb, tw, L, d, cb, dX, pbeta);
+    LAUNCH(kern, dim3(B), dim3(ROW_THREADS), smem, s, X, dF, dXin, sb, tw, L, d, cb, dX, pbeta, cw, pcw);
     return (int)hipGetLastError();
 }
 
@@ -637,7 +647,8 @@ static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* s
         // K2 FrequencyLayer
         DISPATCH_LPR(d, RET(launch_freq_fwd<LPR>(X, w.sqrt_beta, w.filter_ln_w, w.filter_ln_b, c.ln_eps,
                                                  make_drop(*p, c.p_hidden, 1 + 4 * l, tr), p->twiddle, B, L, d,
-                                                 c.cutoff_bins, b.dsp, b.xhat_f, b.rstd_f, s)));
+                                                 c.cutoff_bins, b.dsp, b.xhat_f, b.rstd_f, s,
+                                                 c.filter_kind == 1 ? w.filter_cw : nullptr)));
         // K3 Q, K, V projections (one launch, 3 problems)
         {
             GemmP g = gemm_defaults(T, d, d);
@@ -733,15 +744,25 @@ static int loss_impl(bsarec_plan_t* p, const int64_t* answers, void* stream, boo
 
 extern "C" int bsarec_loss(bsarec_plan_t* p, const int64_t* answers, void* stream) { return loss_impl(p, answers, stream, true); }
 
+static int loss_pair(bsarec_plan_t* p, const int64_t* pos_ids, const int64_t* neg_ids, void* stream, int logsig);
+
 // SASRec's head (sibling model on the same encoder; run the plan with alpha = 0): src/model/sasrec.py:41-63
 extern "C" int bsarec_loss_bce(bsarec_plan_t* p, const int64_t* pos_ids, const int64_t* neg_ids, void* stream) {
+    return loss_pair(p, pos_ids, neg_ids, stream, 0);
+}
+// FMLPRec's head: src/model/fmlprec.py:41-62
+extern "C" int bsarec_loss_logsig(bsarec_plan_t* p, const int64_t* pos_ids, const int64_t* neg_ids, void* stream) {
+    return loss_pair(p, pos_ids, neg_ids, stream, 1);
+}
+
+static int loss_pair(bsarec_plan_t* p, const int64_t* pos_ids, const int64_t* neg_ids, void* stream, int logsig) {
     if (!p || !pos_ids || !neg_ids) return -10;
     hipStream_t s = (hipStream_t)stream;
     const bsarec_config_t& c = p->cfg;
     const int L = c.seq_len, d = c.hidden;
     p->loss_kind = 1; p->bce_pos = pos_ids; p->bce_neg = neg_ids;
     LAUNCH(bce_rows_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->X[c.layers] + (long)(L - 1) * d, (long)L * d, p->P.item_emb,
-           pos_ids, neg_ids, c.batch, d, c.item_size, p->dlogits, p->loss);
+           pos_ids, neg_ids, c.batch, d, c.item_size, p->dlogits, p->loss, logsig);
     return (int)hipGetLastError();
 }
 
@@ -981,7 +1002,8 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
         // ---- FrequencyLayer backward: completes dX of this layer
         if (!p->fused)
             DISPATCH_LPR(d, RET(launch_freq_bwd<LPR>(X, p->dF, p->dXtmp, w.sqrt_beta, p->twiddle, B, L, d, c.cutoff_bins,
-                                                     dXout, p->part_beta, s)));
+                                                     dXout, p->part_beta, s, c.filter_kind == 1 ? w.filter_cw : nullptr,
+                                                     c.filter_kind == 1 ? p->part_cwL[l] : nullptr)));
         dY = dXout;
     }
     // ---- embedding front-end backward

@@ -217,7 +217,8 @@ template <int LPR>
 __global__ void __launch_bounds__(ROW_THREADS)
 freq_fwd_kernel(const float* __restrict__ X, const float* __restrict__ sqrt_beta, const float* __restrict__ gamma,
                 const float* __restrict__ beta, float eps, DropP drop, const float* __restrict__ twg, int L, int d,
-                int cb, float* __restrict__ DSP, float* __restrict__ xhat, float* __restrict__ rstd) {
+                int cb, float* __restrict__ DSP, float* __restrict__ xhat, float* __restrict__ rstd,
+                const float* __restrict__ cw /* FMLPRec: complex_weight [cb][d][2], else null */) {
     constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* tw = fsm;                               // [2L] rounded up to 4
@@ -229,11 +230,22 @@ freq_fwd_kernel(const float* __restrict__ X, const float* __restrict__ sqrt_beta
     __syncthreads();
     auto src = [&](int, int t, int lc) { return ld4(x + (long)t * d + lc); };
     dft_spectrum<LPR, 1>(src, L, d, cb, tw, spec, part);
+    if (cw) {        // sibling model FMLPRec (src/model/fmlprec.py:103-108): Y_k = X_k W_k, then the same inverse transform
+        for (int i = threadIdx.x; i < cb * d; i += ROW_THREADS) {
+            const int k = i / d, c = i - k * d;
+            const float xr = spec[((long)k * 2 + 0) * d + c], xi = spec[((long)k * 2 + 1) * d + c];
+            const float wr = cw[(long)i * 2], wi = cw[(long)i * 2 + 1];
+            spec[((long)k * 2 + 0) * d + c] = xr * wr - xi * wi;
+            spec[((long)k * 2 + 1) * d + c] = xr * wi + xi * wr;
+        }
+        __syncthreads();
+    }
 
     const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
     const bool colok = lc < d;
     f32x4 b2 = {0, 0, 0, 0}, g = b2, be = b2;
     if (colok) { b2 = ld4(sqrt_beta + lc); b2 = b2 * b2; g = ld4(gamma + lc); be = ld4(beta + lc); }
+    if (cw) b2 = f32x4{0, 0, 0, 0};               // f = the filtered signal itself (no high-pass remainder)
     const float invd = 1.0f / (float)d;
     for (int t0 = 0; t0 < L; t0 += RPP) {
         const int t = t0 + lr;
@@ -264,7 +276,9 @@ template <int LPR>
 __global__ void __launch_bounds__(ROW_THREADS)
 freq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dF, const float* __restrict__ dXin,
                 const float* __restrict__ sqrt_beta, const float* __restrict__ twg, int L, int d, int cb,
-                float* __restrict__ dX, float* __restrict__ pbeta /* [B][d] */) {
+                float* __restrict__ dX, float* __restrict__ pbeta /* [B][d] */,
+                const float* __restrict__ cw /* FMLPRec: complex_weight [cb][d][2], else null */,
+                float* __restrict__ pcw /* FMLPRec: per-sequence d(complex_weight) [B][cb][d][2] */) {
     constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* tw = fsm;
@@ -278,12 +292,30 @@ freq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dF, const
     const bool colok = lc < d;
     f32x4 bt = {0, 0, 0, 0};
     if (colok) bt = ld4(sqrt_beta + lc);
-    const f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
+    f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
+    if (cw) { b2 = f32x4{0, 0, 0, 0}; omb2 = f32x4{1, 1, 1, 1}; }
     auto src = [&](int s, int t, int c) {
         const f32x4 v = ld4((s == 0 ? X : dF) + base + (long)t * d + c);
         return s == 0 ? v : v * omb2;
     };
     dft_spectrum<LPR, 2>(src, L, d, cb, tw, spec, part);
+    if (cw) {
+        // sibling model FMLPRec: with D = spectrum of dF, dX = inverse transform of D conj(W) (the same inverse as the
+        // forward's) and d(W)_k = (w_k / L) conj(X_k) D_k per sequence (w_k = 1 for DC / Nyquist, else 2)
+        float* sD = spec + (long)cb * 2 * d;
+        for (int i = threadIdx.x; i < cb * d; i += ROW_THREADS) {
+            const int k = i / d, c = i - k * d;
+            const float xr = spec[((long)k * 2 + 0) * d + c], xi = spec[((long)k * 2 + 1) * d + c];
+            const float dr = sD[((long)k * 2 + 0) * d + c], di = sD[((long)k * 2 + 1) * d + c];
+            const float wr = cw[(long)i * 2], wi = cw[(long)i * 2 + 1];
+            const float wl = ((k == 0 || 2 * k == L) ? 1.0f : 2.0f) / (float)L;
+            pcw[((long)b * cb * d + i) * 2 + 0] = wl * (dr * xr + di * xi);
+            pcw[((long)b * cb * d + i) * 2 + 1] = wl * (di * xr - dr * xi);
+            sD[((long)k * 2 + 0) * d + c] = dr * wr + di * wi;
+            sD[((long)k * 2 + 1) * d + c] = di * wr - dr * wi;
+        }
+        __syncthreads();
+    }
     f32x4 sb = {0, 0, 0, 0};
     for (int t = lr; t < L; t += RPP) {
         if (!colok) continue;
@@ -301,7 +333,7 @@ freq_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dF, const
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < RPP; ++g) s += part[g * W + c];
-        pbeta[(long)b * d + c] = 2.0f * sqrt_beta[c] * s;
+        pbeta[(long)b * d + c] = cw ? 0.f : 2.0f * sqrt_beta[c] * s;        // FMLPRec has no sqrt_beta
     }
 }
 
@@ -659,12 +691,13 @@ loss_mean_kernel(const float* __restrict__ rows, int B, float* __restrict__ out)
 // =============================================================================================
 __global__ void __launch_bounds__(ROW_THREADS)
 bce_rows_kernel(const float* __restrict__ hlast, long hstride, const float* __restrict__ E, const int64_t* __restrict__ pos,
-                const int64_t* __restrict__ neg, int B, int d, int V, float* __restrict__ coef, float* __restrict__ loss_out) {
+                const int64_t* __restrict__ neg, int B, int d, int V, float* __restrict__ coef, float* __restrict__ loss_out,
+                int logsig /* 1: FMLPRec's -log(sigmoid + 1e-24) form over all rows (src/model/fmlprec.py:56-60) */) {
     __shared__ float red[2][ROW_THREADS];
     float lsum = 0.f, cnt = 0.f;
     for (int b = threadIdx.x; b < B; b += ROW_THREADS) {
         int ip = (int)pos[b], in = (int)neg[b];
-        const bool keep = ip != 0;
+        const bool keep = logsig || ip != 0;
         ip = ip < 0 ? 0 : (ip >= V ? V - 1 : ip); in = in < 0 ? 0 : (in >= V ? V - 1 : in);
         const float* h = hlast + (long)b * hstride;
         float xp = 0.f, xn = 0.f;
@@ -675,6 +708,13 @@ bce_rows_kernel(const float* __restrict__ hlast, long hstride, const float* __re
         }
         // softplus(z) = max(z, 0) + log1p(exp(-|z|))
         const float sp = fmaxf(-xp, 0.f) + log1pf(expf(-fabsf(xp))), sn = fmaxf(xn, 0.f) + log1pf(expf(-fabsf(xn)));
+        if (logsig) {
+            const float s1 = 1.0f / (1.0f + expf(-xp)), s2 = 1.0f / (1.0f + expf(-xn));
+            lsum += -logf(s1 + 1e-24f) - logf(1.0f - s2 + 1e-24f); cnt += 1.f;
+            coef[b] = -(s1 * (1.0f - s1)) / (s1 + 1e-24f);
+            coef[B + b] = (s2 * (1.0f - s2)) / (1.0f - s2 + 1e-24f);
+            continue;
+        }
         if (keep) { lsum += sp + sn; cnt += 1.f; }
         coef[b] = keep ? -1.0f / (1.0f + expf(xp)) : 0.f;            // -sigmoid(-xp)
         coef[B + b] = keep ? 1.0f / (1.0f + expf(-xn)) : 0.f;         //  sigmoid(xn)

@@ -48,6 +48,9 @@ def param_shapes(args) -> "OrderedDict[str, Tuple[int, ...]]":
         s[p + "feed_forward.dense_2.bias"] = (d,)
         s[p + "feed_forward.LayerNorm.weight"] = (d,)
         s[p + "feed_forward.LayerNorm.bias"] = (d,)
+    if getattr(args, "filter_kind", 0) == 1:           # sibling model FMLPRec: the learnable complex filter, appended
+        for l in range(args.num_hidden_layers):
+            s[f"item_encoder.blocks.{l}.layer.filter_layer.complex_weight"] = (1, Lq // 2 + 1, d, 2)
     return s
 
 
@@ -69,7 +72,7 @@ class _Plan:
         a = model.args
         self.cfg = L.Config(batch, a.max_seq_length, a.hidden_size, a.num_attention_heads, a.num_hidden_layers,
                             a.item_size, model.cutoff_bins, float(a.alpha), 1e-12, float(a.hidden_dropout_prob),
-                            float(a.attention_probs_dropout_prob))
+                            float(a.attention_probs_dropout_prob), int(getattr(a, "filter_kind", 0)))
         nbytes = lib.bsarec_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise ValueError("configuration not supported by libbsarec_hip (see include/bsarec_hip.h limits: "
@@ -119,7 +122,7 @@ class _LossFn(torch.autograd.Function):
         model, plan = ctx.model, ctx.plan
         model._run_backward(plan)
         g = model._garena * gout
-        return (None, None, None) + tuple(g[o:o + n].view(shp) for (o, n, shp) in model._slices.values())
+        return (None, None, None) + model._grads_in_param_order(g)
 
 
 class BSARecModel(nn.Module):
@@ -135,6 +138,8 @@ class BSARecModel(nn.Module):
         self.args = args
         self.batch_size = getattr(args, "batch_size", 256)              # stored, unused (as in the reference)
         self.cutoff_bins = min(args.c // 2 + 1, args.max_seq_length // 2 + 1)   # src/model/bsarec.py:87,96
+        if getattr(args, "filter_kind", 0) == 1:
+            self.cutoff_bins = args.max_seq_length // 2 + 1                     # src/model/fmlprec.py:99
         shapes = param_shapes(args)
         self._slices: "OrderedDict[str, Tuple[int, int, Tuple[int, ...]]]" = OrderedDict()
         off = 0
@@ -160,6 +165,15 @@ class BSARecModel(nn.Module):
                     mod.add_module(name, _Bag())
                 mod = getattr(mod, name)
             mod.register_parameter(parts[-1], nn.Parameter(arena[o:o + n].view(shp)))
+
+    def _grads_in_param_order(self, g):
+        """Slices of the flat gradient ``g`` in the order ``self.parameters()`` yields them (module registration order;
+        equal to the arena order except for tensors appended to the arena by a sibling model)."""
+        out = []
+        for name, _ in self.named_parameters():
+            o, n, shp = self._slices[name]
+            out.append(g[o:o + n].view(shp))
+        return tuple(out)
 
     def _param_by_key(self, key):
         mod = self
@@ -201,6 +215,8 @@ class BSARecModel(nn.Module):
                 p = self._param_by_key(key)
                 if key.endswith("sqrt_beta"):
                     p.normal_(0.0, 1.0)
+                elif key.endswith("complex_weight"):
+                    p.normal_(0.0, 1.0).mul_(0.02)          # src/model/fmlprec.py:99 (randn * 0.02)
                 elif "LayerNorm.weight" in key:
                     p.fill_(1.0)
                 elif key.endswith(".bias"):
@@ -220,6 +236,9 @@ class BSARecModel(nn.Module):
         for l in range(self.args.num_hidden_layers):
             for f, suffix in L.LAYER_KEYS.items():
                 setattr(t.layer[l], f, ptr(f"item_encoder.blocks.{l}.{suffix}"))
+            for f, suffix in L.OPTIONAL_LAYER_KEYS.items():
+                key = f"item_encoder.blocks.{l}.{suffix}"
+                setattr(t.layer[l], f, ptr(key) if key in self._slices else None)
         return t
 
     def _require_gpu(self):
@@ -388,7 +407,7 @@ class _BCEFn(torch.autograd.Function):
         model, plan = ctx.model, ctx.plan
         model._run_backward(plan)
         g = model._garena * gout
-        return (None, None, None, None) + tuple(g[o:o + n].view(shp) for (o, n, shp) in model._slices.values())
+        return (None, None, None, None) + model._grads_in_param_order(g)
 
 
 class SASRecModel(BSARecModel):
@@ -461,5 +480,96 @@ class SASRecModel(BSARecModel):
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
 
-# src/model/__init__.py:10-19: the hot-path entry and its first sibling on the same kernels
-MODEL_DICT = {"bsarec": BSARecModel, "sasrec": SASRecModel}
+class _LogSigFn(_BCEFn):
+    @staticmethod
+    def forward(ctx, model, ids, pos, neg, *params):
+        plan = model._run_forward(ids, train=model.training, new_step=model.training, last_only=True)
+        model._run_loss_pair(plan, pos, neg)
+        ctx.model, ctx.plan = model, plan
+        return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
+
+
+class FMLPRecModel(BSARecModel):
+    """Sibling model (the "learnable complex filter" of the north star): ``MODEL_DICT['fmlprec']``,
+    src/model/fmlprec.py.  An FMLPRecBlock is a BSARecBlock with alpha = 1 (only the frequency branch reaches the
+    feed-forward) whose filter is ``irfft(rfft(x) * complex_weight)`` instead of BSARec's low-pass / beta^2 mix
+    (``filter_kind = 1``: the generic frequency kernels multiply the spectrum by the weight, all L//2+1 bins kept).
+    The attention tensors and sqrt_beta exist in the arena, receive exactly zero gradient and are neither saved nor
+    loaded; state_dict uses the reference's names (``...layer.complex_weight``, ``...layer.LayerNorm.*``; 4 + 9 N keys).
+    Loss head: -log(sigmoid(x_pos) + 1e-24) - log(1 - sigmoid(x_neg) + 1e-24), mean over the batch (fmlprec.py:41-62).
+    Runs on the generic tiled kernels (the fused per-sequence kernels implement BSARec's filter only)."""
+
+    needs_negatives = True
+
+    def __init__(self, args):
+        import copy
+        a = copy.copy(args)
+        a.alpha = 1.0
+        a.filter_kind = 1
+        if not hasattr(a, "c"):
+            a.c = 3
+        super().__init__(a)
+
+    @staticmethod
+    def _ref_key(k: str):
+        if ".attention_layer." in k or k.endswith("sqrt_beta"):
+            return None
+        return k.replace(".layer.filter_layer.", ".layer.")
+
+    def _ref_order(self):
+        """The reference registers complex_weight first inside a block (fmlprec.py:99-101)."""
+        keys = [k for k in self._slices if self._ref_key(k) is not None]
+        top = [k for k in keys if not k.startswith("item_encoder.")]
+        out = list(top)
+        for l in range(self.args.num_hidden_layers):
+            pre = f"item_encoder.blocks.{l}."
+            blk = [k for k in keys if k.startswith(pre)]
+            cw = [k for k in blk if k.endswith("complex_weight")]
+            out += cw + [k for k in blk if not k.endswith("complex_weight")]
+        return out
+
+    def state_dict(self, *a, **kw):
+        sd = super().state_dict(*a, **kw)
+        return OrderedDict((self._ref_key(k), sd[k]) for k in self._ref_order())
+
+    def load_state_dict(self, state_dict, strict=True):
+        own = super().state_dict()
+        full = OrderedDict((k, v) for k, v in own.items())
+        for k, v in state_dict.items():
+            kk = k.replace(".layer.", ".layer.filter_layer.") if (".layer." in k and ".filter_layer." not in k) else k
+            if kk not in own:
+                if strict:
+                    raise KeyError(f"unexpected key {k}")
+                continue
+            full[kk] = v
+        return super().load_state_dict(full, strict=strict)
+
+    def _run_loss_pair(self, plan, pos, neg):
+        dev = self._arena.device
+        p_ = pos.to(device=dev, dtype=torch.int64).contiguous()
+        n_ = neg.to(device=dev, dtype=torch.int64).contiguous()
+        L.check(plan.lib.bsarec_loss_logsig(plan.handle, p_.data_ptr(), n_.data_ptr(), self._stream()), "bsarec_loss_logsig")
+        plan._pair_keepalive = (p_, n_)
+
+    def calculate_loss(self, input_ids, answers, neg_answers=None, same_target=None, user_ids=None):
+        """src/model/fmlprec.py:41-62."""
+        if neg_answers is None:
+            raise ValueError("FMLPRec's loss needs neg_answers (src/dataset.py:67)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _LogSigFn.apply(self, input_ids, answers, neg_answers, *self.parameters())
+        plan = self._run_forward(input_ids, train=self.training, new_step=self.training, last_only=True)
+        self._run_loss_pair(plan, answers, neg_answers)
+        return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
+
+    def train_step(self, input_ids, answers, neg_answers=None) -> torch.Tensor:
+        if self._adam is None:
+            raise RuntimeError("call configure_adam() first")
+        plan = self._run_forward(input_ids, train=True, new_step=True, last_only=True)
+        self._run_loss_pair(plan, answers, neg_answers)
+        self._run_backward(plan)
+        self.adam_step()
+        return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
+
+# src/model/__init__.py:10-19: the hot-path entry and its siblings on the same kernels
+MODEL_DICT = {"bsarec": BSARecModel, "sasrec": SASRecModel, "fmlprec": FMLPRecModel}

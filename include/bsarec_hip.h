@@ -24,7 +24,7 @@ extern "C" {
 #endif
 
 #define BSAREC_MAX_LAYERS 16
-#define BSAREC_ABI_VERSION 2
+#define BSAREC_ABI_VERSION 3
 
 /* Hyper-parameters the reference model reads from `args`
  * (src/utils.py:83-96; src/model/bsarec.py:71-88; src/model/_modules.py:79-87). */
@@ -40,15 +40,19 @@ typedef struct {
     float ln_eps;       /* 1e-12 */
     float p_hidden;     /* hidden_dropout_prob */
     float p_attn;       /* attention_probs_dropout_prob */
+    int filter_kind;    /* 0: BSARec's FrequencyLayer (low-pass + beta^2 high-pass, src/model/bsarec.py:90-104);
+                         * 1: FMLPRec's learnable complex filter irfft(rfft(x) * W) (src/model/fmlprec.py:96-113): the
+                         *    layer's filter_cw tensor is used, cutoff_bins must be L/2 + 1, generic kernels only */
 } bsarec_config_t;
 
-/* The 19 tensors of one BSARecBlock, in state_dict order
+/* The 19 tensors of one BSARecBlock, in state_dict order (+ the sibling model's filter weight)
  * (item_encoder.blocks.{l}.layer.filter_layer.* , .attention_layer.* , .feed_forward.*). */
 typedef struct {
     float *sqrt_beta, *filter_ln_w, *filter_ln_b;
     float *query_w, *query_b, *key_w, *key_b, *value_w, *value_b, *dense_w, *dense_b;
     float *attn_ln_w, *attn_ln_b;
     float *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b, *ffn_ln_w, *ffn_ln_b;
+    float *filter_cw;   /* filter_kind 1 only: complex_weight [L/2+1, d, 2] (re, im) as the reference stores it; else null */
 } bsarec_layer_t;
 
 /* All 4 + 19 N tensors (parameters, or their gradients) as device pointers.  Linear weights are
@@ -125,6 +129,9 @@ int bsarec_forward_last(bsarec_plan_t *plan, const int64_t *ids, int train, void
  * alpha = 0 (then a BSARecBlock is exactly the reference's TransformerBlock, src/model/_modules.py:142-151).  Loss ->
  * BSAREC_BUF_LOSS; bsarec_backward then back-propagates this head (pos_ids / neg_ids must stay valid until then). */
 int bsarec_loss_bce(bsarec_plan_t *plan, const int64_t *pos_ids, const int64_t *neg_ids, void *stream);
+/* Sibling model FMLPRec's head (src/model/fmlprec.py:41-62): mean over ALL rows of
+ * -log(sigmoid(x_pos) + 1e-24) - log(1 - sigmoid(x_neg) + 1e-24); otherwise as bsarec_loss_bce. */
+int bsarec_loss_logsig(bsarec_plan_t *plan, const int64_t *pos_ids, const int64_t *neg_ids, void *stream);
 
 /* logits only (Trainer.predict_full, src/trainers.py:62-68). */
 int bsarec_logits(bsarec_plan_t *plan, void *stream);

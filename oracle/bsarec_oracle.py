@@ -231,6 +231,43 @@ def lowpass_matrix(L: int, cb: int, dtype=np.float64) -> np.ndarray:
     return (P / L).astype(dtype)
 
 
+def fmlp_filter(x, cw):
+    """FMLPRecLayer's filter (src/model/fmlprec.py:103-108): irfft(rfft(x, dim=1, ortho) * complex_weight, n=L, ortho).
+    ``cw`` is the reference's real view [1, L//2+1, d, 2].  Returns (y, spectrum of x) in x's dtype / complex128."""
+    L = x.shape[1]
+    W = cw[0, :, :, 0].astype(np.float64) + 1j * cw[0, :, :, 1].astype(np.float64)
+    X = np.fft.rfft(x.astype(np.float64), axis=1, norm="ortho")
+    return np.fft.irfft(X * W[None], n=L, axis=1, norm="ortho").astype(x.dtype), X
+
+
+def fmlp_filter_bwd(dy, X, cw):
+    """Backward of fmlp_filter by the real-matrix form of the two transforms: with C[k,t] = cos(2 pi k t / L),
+    S[k,t] = sin(.), w_k = 1 for DC / Nyquist else 2 and the ortho factor 1/sqrt(L) on each side,
+      Xr = C x / sqrt(L), Xi = -S x / sqrt(L), Y = X W, y = (C^T (w Yr) - S^T (w Yi)) / sqrt(L).
+    Returns (dx, d complex_weight in the reference's [1, K, d, 2] layout)."""
+    B, L, d = dy.shape
+    K = L // 2 + 1
+    k = np.arange(K)[:, None]
+    tt = np.arange(L)[None, :]
+    ang = 2.0 * np.pi * k * tt / L
+    C, S = np.cos(ang), np.sin(ang)
+    w = np.full(K, 2.0)
+    w[0] = 1.0
+    if L % 2 == 0:
+        w[-1] = 1.0
+    rs = 1.0 / math.sqrt(L)
+    Wr, Wi = cw[0, :, :, 0].astype(np.float64), cw[0, :, :, 1].astype(np.float64)
+    dy64 = dy.astype(np.float64)
+    gYr = rs * w[None, :, None] * np.einsum("kt,btc->bkc", C, dy64)
+    gYi = -rs * w[None, :, None] * np.einsum("kt,btc->bkc", S, dy64)
+    Xr, Xi = X.real, X.imag
+    gW = np.stack([(gYr * Xr + gYi * Xi).sum(0), (-gYr * Xi + gYi * Xr).sum(0)], axis=-1)[None]
+    gXr = gYr * Wr[None] + gYi * Wi[None]
+    gXi = -gYr * Wi[None] + gYi * Wr[None]
+    dx = rs * (np.einsum("kt,bkc->btc", C, gXr) - np.einsum("kt,bkc->btc", S, gXi))
+    return dx.astype(dy.dtype), gW.astype(cw.dtype)
+
+
 def lowpass(x, cb: int):
     """low = irfft(rfft(x, dim=1, ortho)[:, :cb] zero-extended, n=L, dim=1, ortho)
     (src/model/bsarec.py:93-97).  Self-adjoint, so the same call is its own backward."""
@@ -288,8 +325,13 @@ def forward(params: Dict[str, np.ndarray], cfg: Config, ids: np.ndarray,
         lc: Dict[str, object] = {"x": x}
         # FrequencyLayer                                              bsarec.py:90-104
         beta = P[p + "layer.filter_layer.sqrt_beta"]
-        low = lowpass(x, cb)
-        f = low + (beta ** 2) * (x - low)
+        cwk = p + "layer.filter_layer.complex_weight"
+        if cwk in P:                                   # sibling model FMLPRec: learnable complex filter instead
+            f, lc["Xspec"] = fmlp_filter(x, P[cwk])
+            low = np.zeros_like(x)
+        else:
+            low = lowpass(x, cb)
+            f = low + (beta ** 2) * (x - low)
         fd, lc["keep_f"] = _drop(f, ph, drop, 1 + 4 * l)
         dsp, lc["ln_f"] = layer_norm_fwd(fd + x, P[p + "layer.filter_layer.LayerNorm.weight"],
                                          P[p + "layer.filter_layer.LayerNorm.bias"], cfg.eps)
@@ -360,6 +402,27 @@ def bce_head(pos_ids, neg_ids):
         gp = np.where(keep, -1.0 / (1.0 + np.exp(xp)), 0.0) / n          # d loss / d xp = -sigmoid(-xp) / n
         gn = np.where(keep, 1.0 / (1.0 + np.exp(-xn)), 0.0) / n          # d loss / d xn = sigmoid(xn) / n
         gp, gn = gp.astype(t), gn.astype(t)
+        dE = np.zeros_like(E)
+        np.add.at(dE, pos_ids_, gp[:, None] * h_last)
+        np.add.at(dE, neg_ids_, gn[:, None] * h_last)
+        dh = gp[:, None] * E[pos_ids_] + gn[:, None] * E[neg_ids_]
+        return float(loss), None, dE, dh.astype(t)
+    return head
+
+
+def fmlp_head(pos_ids, neg_ids):
+    """FMLPRecModel.calculate_loss's head (src/model/fmlprec.py:41-62): mean over ALL rows of
+    -log(sigmoid(x_pos) + 1e-24) - log(1 - sigmoid(x_neg) + 1e-24)."""
+    def head(h_last, E, dtype):
+        t = dtype
+        pos_ids_, neg_ids_ = np.asarray(pos_ids), np.asarray(neg_ids)
+        n = len(pos_ids_)
+        xp = (E[pos_ids_] * h_last).sum(-1).astype(np.float64)
+        xn = (E[neg_ids_] * h_last).sum(-1).astype(np.float64)
+        sp, sn = 1.0 / (1.0 + np.exp(-xp)), 1.0 / (1.0 + np.exp(-xn))
+        loss = (-np.log(sp + 1e-24) - np.log(1.0 - sn + 1e-24)).mean()
+        gp = (-(sp * (1 - sp)) / (sp + 1e-24) / n).astype(t)
+        gn = ((sn * (1 - sn)) / (1.0 - sn + 1e-24) / n).astype(t)
         dE = np.zeros_like(E)
         np.add.at(dE, pos_ids_, gp[:, None] * h_last)
         np.add.at(dE, neg_ids_, gn[:, None] * h_last)
@@ -450,8 +513,13 @@ def loss_and_grads(params, cfg: Config, ids, answers, drop: Optional[DropoutSpec
         df = undrop(dzf, lc["keep_f"], sc_h)
         beta = P[flp + "sqrt_beta"]
         b2 = beta ** 2
-        dxl += dzf + b2 * df + lowpass((t(1) - b2) * df, cb)
-        G[flp + "sqrt_beta"] = (t(2) * beta * (df * (x - lc["low"])).reshape(-1, d).sum(0)).reshape(1, 1, d)
+        if flp + "complex_weight" in P:
+            dxf, G[flp + "complex_weight"] = fmlp_filter_bwd(df, lc["Xspec"], P[flp + "complex_weight"])
+            dxl += dzf + dxf
+            G[flp + "sqrt_beta"] = np.zeros_like(beta)
+        else:
+            dxl += dzf + b2 * df + lowpass((t(1) - b2) * df, cb)
+            G[flp + "sqrt_beta"] = (t(2) * beta * (df * (x - lc["low"])).reshape(-1, d).sum(0)).reshape(1, 1, d)
         dx = dxl
         if d_outs is not None:
             dx = dx + d_outs[l]
