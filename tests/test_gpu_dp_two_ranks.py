@@ -1,0 +1,74 @@
+"""Two data-parallel ranks on ONE GPU (gloo backend for the exchange, so that no second device is needed): the
+sharded step -- same permutation on both ranks, rank slice of every global batch, summing all-reduce of the flat
+gradient arena, Adam on sum / world -- must leave both replicas identical and equal to a single process that trains on
+the global batch of 2B (dropout off: the Philox streams are rank-decorrelated by design)."""
+import argparse
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _ns():
+    return argparse.Namespace(item_size=301, hidden_size=64, max_seq_length=50, batch_size=64, hidden_dropout_prob=0.0,
+                              attention_probs_dropout_prob=0.0, num_hidden_layers=2, num_attention_heads=2,
+                              hidden_act="gelu", initializer_range=0.02, c=3, alpha=0.9, seed=42, lr=1e-3,
+                              adam_beta1=0.9, adam_beta2=0.999, weight_decay=0.0, no_cuda=False, log_freq=1)
+
+
+def _table():
+    from bsarec_amd import data as D
+    seqs = D.synth_ml1m_like(seed=3, n_users=40, n_items=300)
+    u, x, a_ = D.train_table(seqs, 50)
+    return u[:1024], x[:1024], a_[:1024]
+
+
+def _worker(rank, world, port, graph, out_dir):
+    import torch.distributed as dist
+    from bsarec_amd import BSARecModel, data as D
+    from bsarec_amd.trainer import Trainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        u, x, a_ = _table()
+        torch.manual_seed(1)
+        model = BSARecModel(_ns()).cuda()
+        model.set_seed(5, rank)
+        dl = D.DeviceBatches(u, x, a_, 64, "cuda", shuffle=True, seed=11, rank=rank, world=world)
+        tr = Trainer(model, dl, None, None, _ns(), None, use_graph=graph, process_group=dist.group.WORLD)
+        tr.dp_graph = "two"                      # gloo's all-reduce cannot be captured: grad graph + eager exchange + Adam graph
+        losses = [float(tr.train(e)["rec_loss"]) for e in range(2)]
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.asarray(losses), **sd)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_ranks_equal_each_other_and_the_global_batch(graph, tmp_path):
+    import torch.multiprocessing as mp
+    from bsarec_amd import BSARecModel, data as D
+    from bsarec_amd.trainer import Trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, graph, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)          # replicas stay bit-identical
+    # single process, global batch = 2 x 64 over the same permutation
+    u, x, a_ = _table()
+    torch.manual_seed(1)
+    model = BSARecModel(_ns()).cuda()
+    model.set_seed(5)
+    dl = D.DeviceBatches(u, x, a_, 128, "cuda", shuffle=True, seed=11)
+    tr = Trainer(model, dl, None, None, _ns(), None, use_graph=False)
+    losses = [float(tr.train(e)["rec_loss"]) for e in range(2)]
+    np.testing.assert_allclose(r0["losses"], losses, atol=2e-4)
+    sd = model.state_dict()
+    for k in sd:
+        got, want = r0[k], sd[k].detach().cpu().numpy()
+        bad = np.abs(got - want) > 2e-5
+        assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - want).max())
