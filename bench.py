@@ -91,13 +91,22 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # BSAREC_DIST_BACKEND=gloo: rehearsal of the N > 1 path with all ranks on ONE GPU (the build box has one); the
+    # exchange then goes through the host, so the step uses grad graph + eager all-reduce + Adam graph
+    backend = os.environ.get("BSAREC_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
+        os.environ.setdefault("BSAREC_DP_GRAPH", "two")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1 or a.dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
         pg = torch.distributed.group.WORLD
 
     from bsarec_amd import BSARecModel, _lib as Lb
@@ -146,7 +155,10 @@ def main():
 
     def barrier():
         if pg is not None:
-            torch.distributed.barrier(device_ids=[local])
+            if backend == "nccl":
+                torch.distributed.barrier(device_ids=[local])
+            else:
+                torch.distributed.barrier()
         torch.cuda.synchronize()
 
     model.train()
