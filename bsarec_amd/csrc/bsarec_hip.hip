@@ -985,12 +985,13 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                         for (int n0 = 0; n0 < q.N; n0 += 64) DW.U[dw_nu++] = DwUnit{(short)dw_np, (short)m0, (short)n0, 0};
                     ++dw_np;
                 }
-                if (!top_pruned) {
+                if (top_pruned) { DW.nsmall = dw_nu; DW.small_slabs = std::min(TOP_SLABS, ns); }
+                else {
                     DW.nunits = dw_nu; DW.nslab = ns;
                     ProfScope prof(BSAREC_K_DW1, s);
-                    LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * dw_nu), dim3(256), 0, s, DW);
+                    LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * (dw_nu - DW.nsmall) + DW.nsmall * DW.small_slabs), dim3(256), 0, s, DW);
                     HIPCHK(hipGetLastError());
-                    dw_np = 0; dw_nu = 0;
+                    dw_np = 0; dw_nu = 0; DW.nsmall = 0; DW.small_slabs = 0;
                 }
             } else {
             constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES;

@@ -42,6 +42,11 @@ struct DwP {
     DwProblem P[DW_MAX_PROB];
     DwUnit U[DW_MAX_UNITS];
     int nunits, nslab;
+    // Units [0, nsmall) belong to the tiny problems of the pruned top block (K = B or B*h rows, `small_slabs` slab
+    // slices each): they take the LAST nsmall * small_slabs workgroups of the grid on their own -- no empty
+    // workgroups; the big problems' 8 * ceil(nslab / 8) * (nunits - nsmall) workgroups come first so that all of them
+    // are resident from the start (480 of the 512 slots at C1), the small ones fill the rest and finish early.
+    int nsmall, small_slabs;
 };
 
 // one k-block (8 token rows) of operand registers: lane half h holds rows 4h .. 4h+3, two columns of each operand
@@ -114,10 +119,18 @@ dw_direct_kernel(const DwP G) {
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All units of
     // one slab slice read the same token rows (X feeds the q/k/v tiles, hmix and dT2 four tiles each), so a slice is
     // kept on ONE XCD and the re-reads hit that L2.
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int slab = xcd + 8 * (j / G.nunits);
-    if (slab >= G.nslab) return;
-    const DwUnit u = G.U[j % G.nunits];
+    int slab, ui;
+    const int nbig = G.nunits - G.nsmall, nbw = 8 * ((G.nslab + 7) >> 3) * nbig;     // big problems first: all resident at once
+    if ((int)blockIdx.x < nbw) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        slab = xcd + 8 * (j / nbig);
+        if (slab >= G.nslab) return;
+        ui = G.nsmall + j % nbig;
+    } else {                                              // the small ones fill the free slots and finish early
+        const int bid = blockIdx.x - nbw;
+        ui = bid % G.nsmall; slab = bid / G.nsmall;
+    }
+    const DwUnit u = G.U[ui];
     const DwProblem& Q = G.P[u.prob];
     if (slab >= Q.nslab) return;
     const int m0 = u.m0, n0 = u.n0;
