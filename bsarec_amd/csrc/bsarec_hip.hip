@@ -24,7 +24,7 @@ static thread_local bool g_dry = false;
 
 static long long* g_stamps = nullptr;   // diagnostic stamp buffer (bsarec_debug_stamps)
 static int g_use_fused = 1;
-#define TOP_SLABS 4                 // slab slices of the pruned top block's weight-gradient products (K = B or B*h rows only)
+static int TOP_SLABS = 2;           // slab slices of the pruned top block's weight-gradient products (K = B or B*h rows only; measured 1/2/4/8 slabs: 0.2115 / 0.2095 / 0.2122 / 0.2130 ms per step); BSAREC_TOP_SLABS
 static int g_prune_top = 1;          // BSAREC_PRUNE_TOP=0: the loss path runs the full top block too
 static int g_use_direct_dw = 1;      // BSAREC_DW=tiled selects the LDS-tiled grouped kernel at the fused shape too      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
 
@@ -282,6 +282,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     p->state = (uint64_t*)state; p->twiddle = twiddle; p->train = false;
     if (const char* e = getenv("BSAREC_DW")) g_use_direct_dw = strcmp(e, "tiled") != 0;
     if (const char* e = getenv("BSAREC_PRUNE_TOP")) { if (atoi(e) == 0) g_prune_top = 0; }
+    if (const char* e = getenv("BSAREC_TOP_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= 16) TOP_SLABS = v; }
     derive(*p);
     size_t total = 0;
     carve(*p, p->ws, &total);
