@@ -166,3 +166,37 @@ def test_data_parallel_gradient_equals_global_batch_gradient_gloo_world2(tmp_pat
     _, _, G, _ = O.loss_and_grads(params, cfg, ids, ans)
     ref = np.concatenate([G[k].reshape(-1) for k in params.keys()])
     assert rel_l2(got, ref) < 1e-5
+
+
+def test_header_is_plain_c_and_links_from_c_and_cpp(tmp_path):
+    """The boundary is a C ABI: include/bsarec_hip.h must compile as C99 and as C++ with nothing but the standard
+    headers, and a host program linked against libbsarec_hip.so must resolve the entry points (only the two calls that
+    need no GPU are made: ABI version and workspace size)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "bsarec_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libbsarec_hip.so")) or not shutil.which("gcc"):
+        pytest.skip("library or gcc missing")
+    src = r"""
+#include "bsarec_hip.h"
+#include <stdio.h>
+int main(void) {
+    bsarec_config_t cfg = {256, 50, 64, 2, 2, 3417, 2, 0.9f, 1e-12f, 0.5f, 0.5f, 0};
+    size_t ws = bsarec_workspace_bytes(&cfg);
+    cfg.hidden = 63;                                   /* not a multiple of 4: rejected */
+    size_t bad = bsarec_workspace_bytes(&cfg);
+    printf("%d %zu %zu\n", bsarec_abi_version(), ws, bad);
+    return (ws > 0 && bad == 0) ? 0 : 1;
+}
+"""
+    for comp, ext, std in (("gcc", "c", "-std=c99"), ("g++", "cpp", "-std=c++11")):
+        f = tmp_path / f"host.{ext}"
+        f.write_text(src)
+        exe = tmp_path / f"host_{ext}"
+        subprocess.run([comp, std, "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(f), "-o", str(exe),
+                        "-L", lib_dir, "-lbsarec_hip", f"-Wl,-rpath,{lib_dir}"], check=True, capture_output=True)
+        r = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        ver, ws, bad = r.stdout.split()
+        assert int(ver) >= 3 and int(ws) > 100_000_000 and int(bad) == 0
