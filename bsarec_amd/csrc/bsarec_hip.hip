@@ -25,6 +25,7 @@ static thread_local bool g_dry = false;
 static long long* g_stamps = nullptr;   // diagnostic stamp buffer (bsarec_debug_stamps)
 static int g_use_fused = 1;
 static int TOP_SLABS = 2;           // slab slices of the pruned top block's weight-gradient products (K = B or B*h rows only; measured 1/2/4/8 slabs: 0.2115 / 0.2095 / 0.2122 / 0.2130 ms per step); BSAREC_TOP_SLABS
+static int g_embed_in_block = 1;    // BSAREC_EMBED_IN_BLOCK=0: separate embedding kernel on the fused path too
 static int g_prune_top = 1;          // BSAREC_PRUNE_TOP=0: the loss path runs the full top block too
 static int g_use_direct_dw = 1;      // BSAREC_DW=tiled selects the LDS-tiled grouped kernel at the fused shape too      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
 
@@ -282,6 +283,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     p->state = (uint64_t*)state; p->twiddle = twiddle; p->train = false;
     if (const char* e = getenv("BSAREC_DW")) g_use_direct_dw = strcmp(e, "tiled") != 0;
     if (const char* e = getenv("BSAREC_PRUNE_TOP")) { if (atoi(e) == 0) g_prune_top = 0; }
+    if (const char* e = getenv("BSAREC_EMBED_IN_BLOCK")) g_embed_in_block = atoi(e) != 0;
     if (const char* e = getenv("BSAREC_TOP_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= 16) TOP_SLABS = v; }
     derive(*p);
     size_t total = 0;
@@ -452,7 +454,7 @@ static int launch_reduce(const ReduceJob* jobs, int njobs, long maxlen, hipStrea
 
 static bool fused_ok(const bsarec_plan& p) { return p.fused; }
 
-static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
+static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const int64_t* ids = nullptr, const GatherP* gp = nullptr) {
     const bsarec_config_t& c = p.cfg;
     const bsarec_layer_t& w = p.P.layer[l];
     LayerBufs& b = p.lb[l];
@@ -467,6 +469,11 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs; F.ctx = b.ctx;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.hmix = b.hmix; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
     F.dsp = nullptr;          // FrequencyLayer output stays in LDS on the fused path (BSAREC_BUF_DSP is generic-path only)
+    if (l == 0 && gp) {       // the embedding front-end rides in the bottom block's phase 0
+        F.e_E = p.P.item_emb; F.e_pos = p.P.pos_emb; F.e_g = p.P.ln_w; F.e_b = p.P.ln_b; F.e_ids = ids; F.e_gp = *gp;
+        F.e_drop = make_drop(p, c.p_hidden, 0, tr); F.e_V = c.item_size;
+        F.e_X0 = p.X[0]; F.e_xhat = p.xhat0; F.e_rstd = p.rstd0; F.e_ids32 = p.ids32;
+    }
     F.L = c.seq_len; F.Lp = p.Lp; F.cb = c.cutoff_bins; F.heads = c.heads;
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
@@ -628,6 +635,8 @@ static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* s
     p->pruned = last_only && p->prune_ok;
     const XformP nox = no_xform();
 
+    const bool embed_in_block = fused_ok(*p) && g_embed_in_block;
+    if (!embed_in_block)
     DISPATCH_LPR(d, {
         constexpr int RPB = ROW_THREADS / LPR;
         LAUNCH(embed_fwd_kernel<LPR>, dim3(cdiv(T, RPB)), dim3(ROW_THREADS), 0, s, ids, gp, p->P.item_emb,
@@ -642,7 +651,7 @@ static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* s
         const float* X = p->X[l];
         if (fused_ok(*p)) {
             if (p->pruned && l == c.layers - 1) RET(launch_top_fwd(*p, l, tr, s));
-            else RET(launch_fused_fwd(*p, l, tr, s));
+            else RET(launch_fused_fwd(*p, l, tr, s, ids, (l == 0 && embed_in_block) ? &gp : nullptr));
             continue;
         }
         // K2 FrequencyLayer

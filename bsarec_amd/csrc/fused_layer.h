@@ -30,6 +30,11 @@ struct FusedFwdP {
     DropP drop_f, drop_p, drop_o, drop_ff;
     float* trash;           // >= 1 KiB scratch: target of the stores of padded rows (keeps the store stream branch-free)
     long long* stamps;      // diagnostic: per-phase s_memtime of workgroup 0 (null in production)
+    // bottom block only (e_E != null): the embedding front-end rides in phase 0 -- batch assembly from the device table
+    // (or ids), E[ids] + Pos, LayerNorm, dropout (src/model/_abstract_model.py:14-24) -> the x tile in LDS, and X[0],
+    // xhat0, rstd0, ids32 to global for the backward
+    const float *e_E, *e_pos, *e_g, *e_b; const int64_t* e_ids; GatherP e_gp; DropP e_drop; int e_V;
+    float *e_X0, *e_xhat, *e_rstd; int* e_ids32;
 };
 
 
@@ -296,6 +301,55 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
         qkv_bias[2] = gld(KARG(FusedFwdP, bv) + col);
     }
     // ---- phase 0: sequence tile, ids, twiddle table -> LDS
+    const float* const eE = KARG(FusedFwdP, e_E);
+    if (eE) {
+        // embedding front-end of this sequence (bottom block): 16 lanes x float4 per token row, 32 rows per pass
+        const GatherP gp = KARG(FusedFwdP, e_gp);
+        const int64_t* const eids = KARG(FusedFwdP, e_ids);
+        const float* const epos = KARG(FusedFwdP, e_pos);
+        const int V = KARG(FusedFwdP, e_V);
+        const float eeps = KARG(FusedFwdP, eps);
+        long src = 0;
+        if (gp.table) {
+            src = *(const AS_GLOBAL long long*)gp.cursor + b;
+            src = src < gp.n ? (long)*(const AS_GLOBAL int64_t*)(gp.perm + src) : 0;
+            if (tid == 0) *(AS_GLOBAL int64_t*)(gp.ans_out + b) = *(const AS_GLOBAL int64_t*)(gp.ans_table + src);
+        }
+        const f32x4 eg = gld4(KARG(FusedFwdP, e_g) + ((tid & 15) << 2)), eb = gld4(KARG(FusedFwdP, e_b) + ((tid & 15) << 2));
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int idx = tid + p * 512, r = idx >> 4, c4 = (idx & 15) << 2;
+            const bool ok = r < L;
+            const long e = (tok0 + r) * 64 + c4;
+            f32x4 v = {0, 0, 0, 0};
+            int id = 0;
+            if (ok) {
+                int64_t id64;
+                if (gp.table) {
+                    id64 = *(const AS_GLOBAL int64_t*)(gp.table + src * L + r);
+                    if (c4 == 0) *(AS_GLOBAL int64_t*)(gp.ids_out + tok0 + r) = id64;
+                } else id64 = *(const AS_GLOBAL int64_t*)(eids + tok0 + r);
+                id = (int)id64;
+                id = id < 0 ? 0 : (id >= V ? V - 1 : id);     // defensive clamp: never read outside the table
+                v = gld4(eE + (long)id * 64 + c4) + gld4(epos + (long)r * 64 + c4);
+            }
+            if (c4 == 0) { sIds[r] = id; if (ok) *(AS_GLOBAL int*)(KARG(FusedFwdP, e_ids32) + tok0 + r) = id; }
+            const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
+            f32x4 dl = {0, 0, 0, 0};
+            if (ok) dl = v - mean;
+            const float var = group_sum<16>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * (1.0f / 64.0f);
+            const float rs = 1.0f / sqrtf(var + eeps);
+            f32x4 y = {0, 0, 0, 0};
+            if (ok) {
+                const f32x4 xh = dl * rs;
+                y = (eg * xh + eb) * drop_mult4(KARG(FusedFwdP, e_drop), (uint64_t)e >> 2);
+                gst4(KARG(FusedFwdP, e_xhat) + e, xh);
+                gst4(KARG(FusedFwdP, e_X0) + e, y);
+                if (c4 == 0) gst(KARG(FusedFwdP, e_rstd) + tok0 + r, rs);
+            }
+            st4(sX + r * FS + c4, y);
+        }
+    } else {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int idx = tid + p * 512, r = idx >> 4, c4 = (idx & 15) << 2;
@@ -304,6 +358,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
         st4(sX + r * FS + c4, v);
     }
     if (tid < 64) sIds[tid] = tid < L ? gldi(R1_ids32 + (tok0 + tid)) : 0;
+    }
     build_twiddle_table(R1_tw, L, cb, sTab);
     lds_barrier();
 

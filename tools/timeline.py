@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Step timeline from a rocprofv3 --kernel-trace csv: python tools/timeline.py <kernel_trace.csv> [steps_to_average]
-Steps are delimited by embed_fwd_kernel; for each kernel position in the step prints the average start offset,
+Steps are delimited by the first kernel of a step (embed_fwd_kernel, or fused_layer_fwd_kernel when the embedding rides in it); for each kernel position in the step prints the average start offset,
 duration and the gap to the previous kernel's end (negative = overlap), plus the queue it ran on."""
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 nst = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = [re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "")) for r in rows]
+first = "embed_fwd_kernel" if any(n.startswith("embed_fwd_kernel") for n in names) else "fused_layer_fwd_kernel"
 steps, cur = [], None
 for r in rows:
     n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", ""))[:44]
-    if n.startswith("embed_fwd_kernel"):
+    if n.startswith(first):
         cur = []
         steps.append(cur)
     if cur is not None:
