@@ -185,7 +185,7 @@ static void derive(bsarec_plan& p) {
     p.kchunk = (int)ch;
     p.nsplit = cdiv(p.T, p.kchunk);
     // split-K over the catalogue for d(h_last) = dlogits . E
-    long vc = rup(cdiv(p.Vp, 16), GEMM_BK);
+    long vc = rup(cdiv(p.Vp, p.fused ? 32 : 16), GEMM_BK);     // 32 catalogue slices for the direct kernel of the fused shape
     if (vc < 64) vc = 64;
     p.vchunk = (int)vc;
     p.vsplit = cdiv(p.Vp, p.vchunk);
@@ -798,11 +798,26 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
     const SlabMap sm = slab_map(d);
     const int ns = p->nsplit, nb = p->nblk;
     const float* hlast = p->X[N] + (long)(L - 1) * d;
+    const bool direct_logits = p->fused && g_use_direct_dw && p->loss_kind == 0 && (long)B * p->Vp * 4 < (1L << 30);
 
     if (p->loss_kind == 1) {     // SASRec's BCE pair: two embedding rows per sequence instead of the dense logits path
         if (!g_dry) HIPCHK(hipMemsetAsync(p->G.item_emb, 0, (size_t)c.item_size * d * sizeof(float), s));
         LAUNCH(bce_bwd_kernel, dim3(B), dim3(64), 0, s, hlast, (long)L * d, p->P.item_emb, p->bce_pos, p->bce_neg, p->dlogits, B, d,
                c.item_size, p->dlast_slab, p->G.item_emb);
+        HIPCHK(hipGetLastError());
+    } else if (direct_logits) {
+        // fused shape: dE = dlogits^T . h_last (K = B rows, written straight into the gradient buffer) and the split-K
+        // slabs of d(h_last) = dlogits . E by the direct kernels (dw_direct.h), one launch
+        DwProblem q;
+        memset(&q, 0, sizeof(q));
+        q.A = p->dlogits; q.B = hlast; q.lda = p->Vp; q.ldb = (long)L * d; q.M = c.item_size; q.N = d; q.K = B;
+        q.kchunk = (int)rup(B, 32); q.nslab = 1; q.slab = p->G.item_emb; q.bslab = nullptr; q.gelu = 0;
+        DhP H;
+        memset(&H, 0, sizeof(H));
+        H.A = p->dlogits; H.lda = p->Vp; H.E = p->P.item_emb; H.B = B; H.V = c.item_size; H.kchunk = p->vchunk;
+        H.nsplit = p->vsplit; H.slab = p->dlast_slab;
+        const int tiles = cdiv(c.item_size, 64);
+        LAUNCH(logits_bwd_direct_kernel, dim3(tiles + cdiv(cdiv(B, 32) * p->vsplit, 4)), dim3(256), 0, s, q, tiles, H);
         HIPCHK(hipGetLastError());
     } else
     // dE (dense, logits path) = dlogits^T . h_last  [V, d] (overwrites the gradient buffer) and the split-K slabs of

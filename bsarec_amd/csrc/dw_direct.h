@@ -110,30 +110,11 @@ __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buff
     }
 }
 
-// The host builds the unit table (64 x 64 tiles of the six problems: 4 + 4 + 4 = 12 units at hidden = 64).
-__global__ void __launch_bounds__(256)
-dw_direct_kernel(const DwP G) {
-    __shared__ __attribute__((aligned(16))) float red[3][66][64];      // accumulators (64) + bias sums (2) of waves 1..3
+// One workgroup = one (problem, 64 x 64 tile, slab slice): its 4 waves take the 4 quarters of the slice, meet in LDS,
+// wave 0 writes the slab.
+__device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, int slab, float (*red)[66][64]) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All units of
-    // one slab slice read the same token rows (X feeds the q/k/v tiles, hmix and dT2 four tiles each), so a slice is
-    // kept on ONE XCD and the re-reads hit that L2.
-    int slab, ui;
-    const int nbig = G.nunits - G.nsmall, nbw = 8 * ((G.nslab + 7) >> 3) * nbig;     // big problems first: all resident at once
-    if ((int)blockIdx.x < nbw) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        slab = xcd + 8 * (j / nbig);
-        if (slab >= G.nslab) return;
-        ui = G.nsmall + j % nbig;
-    } else {                                              // the small ones fill the free slots and finish early
-        const int bid = blockIdx.x - nbw;
-        ui = bid % G.nsmall; slab = bid / G.nsmall;
-    }
-    const DwUnit u = G.U[ui];
-    const DwProblem& Q = G.P[u.prob];
-    if (slab >= Q.nslab) return;
-    const int m0 = u.m0, n0 = u.n0;
     // this wave's quarter of the slab slice
     const int sub = Q.kchunk >> 2;                                       // multiple of 8
     const int kbeg = slab * Q.kchunk + wv * sub, kend = min(Q.K, kbeg + sub);
@@ -195,7 +176,107 @@ dw_direct_kernel(const DwP G) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 2 * (rho(r) + 4 * half) + i;
-            gst2(C + (long)m * Q.N + n0 + 2 * l31, f32x2{acc[i][0][r], acc[i][1][r]});
+            if (m < Q.M) gst2(C + (long)m * Q.N + n0 + 2 * l31, f32x2{acc[i][0][r], acc[i][1][r]});
         }
-    if (n0 == 0 && half == 0) gst2(Q.bslab + (long)slab * Q.M + m0 + 2 * l31, bs);
+    if (Q.bslab && n0 == 0 && half == 0 && m0 + 2 * l31 + 1 < Q.M) gst2(Q.bslab + (long)slab * Q.M + m0 + 2 * l31, bs);
 }
+
+
+// The host builds the unit table (64 x 64 tiles of the six problems: 4 + 4 + 4 = 12 units at hidden = 64).
+__global__ void __launch_bounds__(256)
+dw_direct_kernel(const DwP G) {
+    __shared__ __attribute__((aligned(16))) float red[3][66][64];      // accumulators (64) + bias sums (2) of waves 1..3
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All units of
+    // one slab slice read the same token rows (X feeds the q/k/v tiles, hmix and dT2 four tiles each), so a slice is
+    // kept on ONE XCD and the re-reads hit that L2.
+    int slab, ui;
+    const int nbig = G.nunits - G.nsmall, nbw = 8 * ((G.nslab + 7) >> 3) * nbig;     // big problems first: all resident at once
+    if ((int)blockIdx.x < nbw) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        slab = xcd + 8 * (j / nbig);
+        if (slab >= G.nslab) return;
+        ui = G.nsmall + j % nbig;
+    } else {                                              // the small ones fill the free slots and finish early
+        const int bid = blockIdx.x - nbw;
+        ui = bid % G.nsmall; slab = bid / G.nsmall;
+    }
+    const DwUnit u = G.U[ui];
+    const DwProblem& Q = G.P[u.prob];
+    if (slab >= Q.nslab) return;
+    dw_wg_body(Q, u.m0, u.n0, slab, red);
+}
+
+// =============================================================================================
+// d(h_last) = dlogits . E, split-K over the catalogue, the same way: a wave owns 32 batch rows x 64 features and one
+// catalogue slice.  dlogits is row-major [B][Vp]: lane (l31, half) takes 4 consecutive catalogue columns of batch row
+// 32 mt + l31 with ONE 16-byte load per k-block; E is k-major [V][64]: 8-byte loads feed the two interleaved 32-column
+// tiles (column 2 l31 + j).  Slab [split][B][64]; the consumer (top block backward) adds the splits.
+// =============================================================================================
+struct DhP {
+    const float* A; long lda;          // dlogits [B][lda]
+    const float* E;                    // [V][64]
+    int B, V, kchunk, nsplit;          // kchunk: catalogue columns per split, multiple of 8
+    float* slab;                       // [nsplit][B][64]
+};
+
+__device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    const int mtiles = (G.B + 31) >> 5;
+    const int unit = wg * 4 + wv, mt = unit % mtiles, split = unit / mtiles;
+    if (split >= G.nsplit) return;
+    const int kbeg = split * G.kchunk, kend = min(G.V, kbeg + G.kchunk);
+    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * DW_STAGES - 1) / (8 * DW_STAGES)) * DW_STAGES : 0;
+    const int m = min(32 * mt + l31, G.B - 1);                       // rows past B re-read the last row; never stored
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if (nkb > 0) {
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)G.A, 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)G.E, 0, 0x7FFFFFFF, 0x00020000);
+        const int voa = (int)((long)m * G.lda * 4) + 16 * half, vob = 4 * half * 256 + 8 * l31;      // bytes
+        int soa = kbeg * 4, sob = kbeg * 256, ccol = kbeg + 4 * half;
+        f32x4 sa[DW_STAGES]; f32x2 sb[DW_STAGES][4];
+        auto issue = [&](int u) {
+            sa[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa, soa, 0));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sb[u][s] = bld2(rb, vob, sob + s * 256);
+            soa += 32; sob += 8 * 256;
+        };
+#pragma unroll
+        for (int u = 0; u < DW_STAGES; ++u) issue(u);
+        for (int kb = 0; kb < nkb; kb += DW_STAGES) {
+#pragma unroll
+            for (int u = 0; u < DW_STAGES; ++u) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float a = ccol + s < kend ? sa[u][s] : 0.f;      // columns past the slice (other splits' / next row's data)
+                    const f32x2 b = sb[u][s];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
+                }
+                ccol += 8;
+                __builtin_amdgcn_sched_barrier(0);
+                issue(u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    float* C = G.slab + (long)split * G.B * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * mt + rho(r) + 4 * half;
+        if (row < G.B) gst2(C + (long)row * 64 + 2 * l31, f32x2{acc0[r], acc1[r]});
+    }
+}
+
+// The whole logits backward at the fused shape in ONE launch: workgroups [0, tiles) form dE = dlogits^T . h_last (the
+// dense gradient of the item table, written straight into the gradient buffer: problem Q, 64-row tiles, rows >= M not
+// stored), the rest form the split-K slabs of d(h_last).
+__global__ void __launch_bounds__(256)
+logits_bwd_direct_kernel(const DwProblem Q, int tiles, const DhP H) {
+    __shared__ __attribute__((aligned(16))) float red[3][66][64];
+    if ((int)blockIdx.x < tiles) dw_wg_body(Q, 64 * (int)blockIdx.x, 0, 0, red);
+    else dh_wave_body(H, (int)blockIdx.x - tiles);
+}
+
