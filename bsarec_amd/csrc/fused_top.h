@@ -227,7 +227,10 @@ top_fwd_kernel(const TopFwdP P) {
     if (tid < 64) {                               // ctx_last[c] = sum_j Drop(p)_j v_j[c]
         const int c = tid, head = c / DH;
         float acc = 0.f;
-        for (int j = 0; j < L; ++j) acc += sPd[head * 64 + j] * sV[j * FS + c];
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};          // 64 padded keys (Drop(p) = 0 past L): fixed trip count, 4 chains
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) a4[j & 3] += sPd[head * 64 + j] * sV[j * FS + c];
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         sCtx[c] = acc;
         gst(P.ctx + el + c, acc);
     }
@@ -485,7 +488,10 @@ top_bwd_kernel(const TopBwdP P) {
     if (tid < 64) {
         const int c = tid, head = c / DH;
         float acc = 0.f;
-        for (int j = 0; j < L; ++j) acc += sDs[head * 64 + j] * sK[j * FS + c];
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};          // 64 padded keys (ds = 0 past L, tiles zero-filled): fixed trip count
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) a4[j & 3] += sDs[head * 64 + j] * sK[j * FS + c];
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         sDQ[c] = acc;
         gst(P.dq + (long)b * 64 + c, acc);
         gst(P.pbk + (long)b * 64 + c, sQ[c] * sSum[head]);
@@ -494,7 +500,14 @@ top_bwd_kernel(const TopBwdP P) {
     if (hv) {
         const int head = wave, i = lane, o = tid;
         float rk = 0.f, rv = 0.f;
-        for (int j = 0; j < L; ++j) { const float x = sX[j * FS + i]; rk += sDs[head * 64 + j] * x; rv += sPd[head * 64 + j] * x; }
+        float rk2 = 0.f, rv2 = 0.f;
+#pragma unroll 16
+        for (int j = 0; j < 64; j += 2) {               // fixed trip count, two chains each
+            const float x0 = sX[j * FS + i], x1 = sX[(j + 1) * FS + i];
+            rk += sDs[head * 64 + j] * x0; rv += sPd[head * 64 + j] * x0;
+            rk2 += sDs[head * 64 + j + 1] * x1; rv2 += sPd[head * 64 + j + 1] * x1;
+        }
+        rk += rk2; rv += rv2;
         const long e = ((long)b * heads + head) * 64 + i;
         const bool mine = i / DH == head;
         gst(P.rk + e, rk); gst(P.rv + e, rv);
