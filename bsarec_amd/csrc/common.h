@@ -51,6 +51,30 @@ __device__ __forceinline__ f32x4 drop_mult4(const DropP& d, uint64_t grp) {
     return m;
 }
 
+// The Philox seed and step read ONCE per kernel.  drop_mult4(d, grp) reads them from the device state at every call:
+// two global loads, i.e. a round trip on the critical path of a latency-bound kernel that also waits for every load
+// issued before it (loads return in issue order) -- weight prefetches in flight get drained at each dropout site.
+struct DropSeed { uint32_t k0, k1, step; };
+__device__ __forceinline__ DropSeed drop_seed(const DropP& d) {
+    DropSeed s = {0u, 0u, 0u};
+    if (d.rng) {
+        const __attribute__((address_space(1))) uint64_t* rng = (const __attribute__((address_space(1))) uint64_t*)d.rng;
+        const uint64_t seed = rng[0];
+        s.k0 = (uint32_t)seed; s.k1 = (uint32_t)(seed >> 32); s.step = (uint32_t)rng[1];
+    }
+    return s;
+}
+__device__ __forceinline__ f32x4 drop_mult4(const DropP& d, const DropSeed& sd, uint64_t grp) {
+    f32x4 m = {d.scale, d.scale, d.scale, d.scale};
+    if (d.thresh == 0) return m;
+    const uint4 w = philox4x32_10((uint32_t)grp, (uint32_t)(grp >> 32), d.site, sd.step, sd.k0, sd.k1);
+    m.x = w.x >= d.thresh ? d.scale : 0.f;
+    m.y = w.y >= d.thresh ? d.scale : 0.f;
+    m.z = w.z >= d.thresh ? d.scale : 0.f;
+    m.w = w.w >= d.thresh ? d.scale : 0.f;
+    return m;
+}
+
 // ---------------------------------------------------------------------------------------------
 // erf-GELU as the reference writes it, x * 0.5 * (1 + erf(x / sqrt(2)))  (src/model/_modules.py:56), and its
 // derivative.  erf is the degree-13/8 odd/even rational minimax on [-4, 4] (|error| <= 4.5e-7 absolute,

@@ -198,7 +198,7 @@ __device__ __forceinline__ void load_wT8(const float* __restrict__ gw, f32x4 (&w
 template <bool MIX>
 __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, const float* __restrict__ tileB,
                                            const float* __restrict__ bias, const float* __restrict__ resid,
-                                           const DropP& drop, const float* __restrict__ gamma,
+                                           const DropP& drop, const DropSeed& dseed, const float* __restrict__ gamma,
                                            const float* __restrict__ beta, float eps, const float* __restrict__ dsp,
                                            float alpha, float oma, long tok0, int L, float* __restrict__ outL,
                                            float* __restrict__ outG, float* __restrict__ xhatG, float* __restrict__ rstdG) {
@@ -209,7 +209,7 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, cons
         const bool ok = r < L;
         const long e = (tok0 + r) * 64 + lc;
         f32x4 v = {0, 0, 0, 0};
-        if (ok) v = (ld4(tileA + r * FS + lc) + ld4(tileB + r * FS + lc) + bi) * drop_mult4(drop, (uint64_t)e >> 2) +
+        if (ok) v = (ld4(tileA + r * FS + lc) + ld4(tileB + r * FS + lc) + bi) * drop_mult4(drop, dseed, (uint64_t)e >> 2) +
                     ld4(resid + r * FS + lc);
         const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
         f32x4 dl = {0, 0, 0, 0};
@@ -287,6 +287,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     float* const trash = KARG(FusedFwdP, trash) + 4 * lane;
 
     STAMP(0);
+    const DropSeed dseed = drop_seed(KARG(FusedFwdP, drop_f));     // first loads of the kernel
     const auto R1_X = KARG(FusedFwdP, X);
     const auto R1_ids32 = KARG(FusedFwdP, ids32);
     const auto R1_tw = KARG(FusedFwdP, tw);
@@ -342,7 +343,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
             f32x4 y = {0, 0, 0, 0};
             if (ok) {
                 const f32x4 xh = dl * rs;
-                y = (eg * xh + eb) * drop_mult4(KARG(FusedFwdP, e_drop), (uint64_t)e >> 2);
+                y = (eg * xh + eb) * drop_mult4(KARG(FusedFwdP, e_drop), dseed, (uint64_t)e >> 2);
                 gst4(KARG(FusedFwdP, e_xhat) + e, xh);
                 gst4(KARG(FusedFwdP, e_X0) + e, y);
                 if (c4 == 0) gst(KARG(FusedFwdP, e_rstd) + tok0 + r, rs);
@@ -353,8 +354,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int idx = tid + p * 512, r = idx >> 4, c4 = (idx & 15) << 2;
-        f32x4 v = {0, 0, 0, 0};
-        if (r < L) v = gld4(R1_X + (tok0 + r) * 64 + c4);
+        f32x4 v = gld4(R1_X + (tok0 + min(r, L - 1)) * 64 + c4);
+        if (r >= L) v = f32x4{0, 0, 0, 0};
         st4(sX + r * FS + c4, v);
     }
     if (tid < 64) sIds[tid] = tid < L ? gldi(R1_ids32 + (tok0 + tid)) : 0;
@@ -459,7 +460,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
                 if (ok) {
                     const f32x4 xv = ld4(sX + t * FS + lc);
                     const f32x4 low = lowpass_tab(sSpec, t, lc, L, cb, sTab);
-                    v = (low + b2 * (xv - low)) * drop_mult4(R2_drop_f, (uint64_t)e >> 2) + xv;
+                    v = (low + b2 * (xv - low)) * drop_mult4(R2_drop_f, dseed, (uint64_t)e >> 2) + xv;
                 }
                 const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
                 f32x4 dl = {0, 0, 0, 0};
@@ -566,7 +567,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
                     if (query < L && key0 < Lp) {
                         const long e = (((long)b * heads + head) * L + query) * Lp + key0;
                         gst4(R3_probs + e, p);
-                        m = drop_mult4(R3_drop_p, (uint64_t)e >> 2);
+                        m = drop_mult4(R3_drop_p, dseed, (uint64_t)e >> 2);
                     }
                     p = p * m;
                     st[4 * g] = p.x; st[4 * g + 1] = p.y; st[4 * g + 2] = p.z; st[4 * g + 3] = p.w;
@@ -639,7 +640,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
     lds_barrier();
-    ln_rows_64<true>(sQ, sK, R4_bo, sX, R4_drop_o, R4_a_g, R4_a_b, R4_eps, sD, R4_alpha, R4_oma, tok0, L, sH, R4_hmix, R4_xhat_a,
+    ln_rows_64<true>(sQ, sK, R4_bo, sX, R4_drop_o, dseed, R4_a_g, R4_a_b, R4_eps, sD, R4_alpha, R4_oma, tok0, L, sH, R4_hmix, R4_xhat_a,
                      R4_rstd_a);
     lds_barrier();
 
@@ -708,7 +709,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     const auto R7_ff_g = KARG(FusedFwdP, ff_g);
     const auto R7_rstd_ff = KARG(FusedFwdP, rstd_ff);
     const auto R7_xhat_ff = KARG(FusedFwdP, xhat_ff);
-    ln_rows_64<false>(sX, sE, R7_b2, sH, R7_drop_ff, R7_ff_g, R7_ff_b, R7_eps, nullptr, 0.f, 1.f, tok0, L, nullptr, R7_Xout,
+    ln_rows_64<false>(sX, sE, R7_b2, sH, R7_drop_ff, dseed, R7_ff_g, R7_ff_b, R7_eps, nullptr, 0.f, 1.f, tok0, L, nullptr, R7_Xout,
                       R7_xhat_ff, R7_rstd_ff);
     STAMP(8);
 }
@@ -825,6 +826,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     float* const trash = KARG(FusedBwdP, trash) + 4 * lane;
 
     STAMP(0);
+    const DropSeed dseed = drop_seed(KARG(FusedBwdP, drop_f));     // first loads of the kernel
     const auto R1_dT = KARG(FusedBwdP, dT);
     const auto R1_dY = KARG(FusedBwdP, dY);
     const auto R1_dh_nsplit = KARG(FusedBwdP, dh_nsplit);
@@ -841,35 +843,46 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     f32x4 wA[8], wB[8];
     load_wT8<256>(R1_w2 + (long)(4 * half) * 256 + 128 * grp + col, wA);          // first dU block of this group
     build_twiddle_table(R1_tw, L, cb, sTab);
-    {   // pre-activation tile u [64][256] -> LDS (whole rows, 16 B per lane); consumed by stage A2
-        const float* gu = KARG(FusedBwdP, u);
-        for (int idx = tid; idx < 64 * 64; idx += 512) {
-            const int r = idx >> 6, c4 = (idx & 63) << 2;
-            f32x4 v = {0, 0, 0, 0};
-            if (r < L) v = gld4(gu + (tok0 + r) * 256 + c4);
-            st4(sdU + r * FU + c4, v);
+    // stage A1's operands are requested BEFORE the u tile: loads return in issue order, so the LayerNorm row pass waits
+    // only for them while the 64 KB of u are still in flight
+    const f32x4 g = gld4(R1_ff_g + lc);
+    f32x4 dy[2], xh[2];
+    float rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 32 * i + lr;
+        const long e = (tok0 + r) * 64 + lc;
+        dy[i] = f32x4{0, 0, 0, 0}; xh[i] = dy[i]; rs[i] = 0.f;
+        if (R1_dh_slabs) {                              // only the last position feeds the loss (bsarec.py:32)
+            if (r < L) {
+                if (r == L - 1)
+                    for (int sp = 0; sp < R1_dh_nsplit; ++sp) dy[i] += gld4(R1_dh_slabs + sp * R1_dh_stride + (long)b * 64 + lc);
+                xh[i] = gld4(R1_xhat_ff + e); rs[i] = gld(R1_rstd_ff + tok0 + r);
+            }
+        } else {                                        // branch-free (rows past L re-read row L-1, then zeroed)
+            const bool ok = r < L;
+            const long ec = (tok0 + min(r, L - 1)) * 64 + lc;
+            const f32x4 d4 = gld4(R1_dY + ec), x4 = gld4(R1_xhat_ff + ec);
+            const float r1 = gld(R1_rstd_ff + tok0 + min(r, L - 1));
+            dy[i] = ok ? d4 : f32x4{0, 0, 0, 0}; xh[i] = ok ? x4 : f32x4{0, 0, 0, 0}; rs[i] = ok ? r1 : 0.f;
         }
+    }
+    f32x4 uv[8];
+    {   // pre-activation tile u [64][256] -> registers now, LDS after stage A1's row pass; consumed by stage A2
+        const float* gu = KARG(FusedBwdP, u);
+        // branch-free: a predicated load becomes a branch and the loop then waits for every load before issuing the next
+        // (8 serial round trips); rows past L re-read row L-1 (a valid address) and are zeroed on the way to LDS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * 512, r = idx >> 6, c4 = (idx & 63) << 2;
+            uv[i] = gld4(gu + (tok0 + min(r, L - 1)) * 256 + c4);
+        }
+        // (the tile goes to LDS after the LayerNorm row pass below: its 64 KB arrive while that pass computes)
     }
 
     // ---- stage A1: FeedForward LayerNorm backward (row pass): dz -> sAcc, dT2 -> sT, global
     {
-        const f32x4 g = gld4(R1_ff_g + lc);
         f32x4 sg = {0, 0, 0, 0}, sb = sg;
-        f32x4 dy[2], xh[2];
-        float rs[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = 32 * i + lr;
-            const long e = (tok0 + r) * 64 + lc;
-            dy[i] = f32x4{0, 0, 0, 0}; xh[i] = dy[i]; rs[i] = 0.f;
-            if (r < L) {
-                if (R1_dh_slabs) {                          // only the last position feeds the loss (bsarec.py:32)
-                    if (r == L - 1)
-                        for (int sp = 0; sp < R1_dh_nsplit; ++sp) dy[i] += gld4(R1_dh_slabs + sp * R1_dh_stride + (long)b * 64 + lc);
-                } else dy[i] = gld4(R1_dY + e);
-                xh[i] = gld4(R1_xhat_ff + e); rs[i] = gld(R1_rstd_ff + tok0 + r);
-            }
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * i + lr;
@@ -881,12 +894,17 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             const f32x4 dz = rs[i] * (gg - m1 - xh[i] * m2);
             sg += dy[i] * xh[i]; sb += dy[i];
             f32x4 dt = {0, 0, 0, 0};
-            if (ok) { dt = dz * drop_mult4(R1_drop_ff, (uint64_t)e >> 2); gst4(R1_dT + e, dt); }
+            if (ok) { dt = dz * drop_mult4(R1_drop_ff, dseed, (uint64_t)e >> 2); gst4(R1_dT + e, dt); }
             st4(sAcc + r * FS + lc, dz);
             st4(sT + r * FS + lc, dt);
         }
         seq_partial_64(sg, sPm, R1_pg_ff + (long)b * 64);
         seq_partial_64(sb, sPm, R1_pb_ff + (long)b * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 512, r = idx >> 6, c4 = (idx & 63) << 2;
+        st4(sdU + r * FU + c4, r < L ? uv[i] : f32x4{0, 0, 0, 0});
     }
     lds_barrier();
 
@@ -974,13 +992,13 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * i + lr;
             const long e = (tok0 + r) * 64 + lc;
-            f32x4 q4 = {0, 0, 0, 0}, k4 = q4, v4 = q4;
-            xa[i] = q4; xf[i] = q4; ra[i] = 0.f; rf[i] = 0.f;
-            if (r < L) {
-                xa[i] = gld4(R4_xhat_a + e); ra[i] = gld(R4_rstd_a + tok0 + r);
-                xf[i] = gld4(R4_xhat_f + e); rf[i] = gld(R4_rstd_f + tok0 + r);
-                q4 = gld4(R4_q + e); k4 = gld4(R4_k + e); v4 = gld4(R4_v + e);
-            }
+            const bool okl = r < L;                         // branch-free loads: rows past L re-read row L-1, then zeroed
+            const long ec = (tok0 + min(r, L - 1)) * 64 + lc;
+            const f32x4 z4 = {0, 0, 0, 0};
+            f32x4 q4 = gld4(R4_q + ec), k4 = gld4(R4_k + ec), v4 = gld4(R4_v + ec);
+            xa[i] = gld4(R4_xhat_a + ec); xf[i] = gld4(R4_xhat_f + ec);
+            ra[i] = gld(R4_rstd_a + tok0 + min(r, L - 1)); rf[i] = gld(R4_rstd_f + tok0 + min(r, L - 1));
+            if (!okl) { q4 = z4; k4 = z4; v4 = z4; xa[i] = z4; xf[i] = z4; ra[i] = 0.f; rf[i] = 0.f; }
             st4(sQ + r * FS + lc, q4); st4(sK + r * FS + lc, k4); st4(sV + r * FS + lc, v4);
         }
 #pragma unroll
@@ -1000,8 +1018,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             sga += dya * xa[i]; sba += dya; sgf += dyf * xf[i]; sbf += dyf;
             f32x4 dO = {0, 0, 0, 0}, dF = dO;
             if (ok) {
-                dO = dza * drop_mult4(R4_drop_o, (uint64_t)e >> 2);
-                dF = dzf * drop_mult4(R4_drop_f, (uint64_t)e >> 2);
+                dO = dza * drop_mult4(R4_drop_o, dseed, (uint64_t)e >> 2);
+                dF = dzf * drop_mult4(R4_drop_f, dseed, (uint64_t)e >> 2);
                 gst4(R4_dO + e, dO);
             }
             st4(sAcc + r * FS + lc, dza + dzf);
@@ -1063,7 +1081,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                     if (query < L && key0 < Lp) {
                         const long e = (((long)b * heads + head) * L + query) * Lp + key0;
                         pp[g] = gld4(R6_probs + e);
-                        mm[g] = drop_mult4(R6_drop_p, (uint64_t)e >> 2);
+                        mm[g] = drop_mult4(R6_drop_p, dseed, (uint64_t)e >> 2);
                     }
                 }
 #pragma unroll
@@ -1206,8 +1224,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * i + lr;
-            f32x4 x = {0, 0, 0, 0};
-            if (r < L) x = gld4(R8_X + (tok0 + r) * 64 + lc);
+            f32x4 x = gld4(R8_X + (tok0 + min(r, L - 1)) * 64 + lc);
+            if (r >= L) x = f32x4{0, 0, 0, 0};
             st4(sG + r * FS + lc, ld4(sG + r * FS + lc) + ld4(sPm + r * FS + lc) + ld4(sAcc + r * FS + lc));
             st4(sXin + r * FS + lc, x);
         }
@@ -1274,7 +1292,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                 const f32x4 lowg = lowpass_tab(spec + cb * 128, t, lc, L, cb, sTab);
                 dx = ld4(sG + t * FS + lc) + b2 * df + lowg;
                 sb += df * (xv - lowx);
-                if (e_dz) { xh = gld4(e_xhat + e); rs = gld(e_rstd + tok0 + t); dx = dx * drop_mult4(e_drop, (uint64_t)e >> 2); }
+                if (e_dz) { xh = gld4(e_xhat + e); rs = gld(e_rstd + tok0 + t); dx = dx * drop_mult4(e_drop, dseed, (uint64_t)e >> 2); }
                 else gst4(R8_dX + e, dx);
             }
             if (e_dz) {                                     // embedding LayerNorm backward on the finished row

@@ -25,19 +25,7 @@ struct TopFwdP {
     long long* stamps;             // diagnostic: per-step shader clock of workgroup 0 (null in production)
 };
 
-// keep-mask x scale of ONE element (common.h: drop_mult4).  The Philox seed and step are read from the device state
-// once per kernel (DropSeed) -- drop_mult4 reads them at every call, a global round trip that in these single-row
-// chains would sit on the critical path behind whatever bulk prefetch was issued before it.
-struct DropSeed { uint32_t k0, k1, step; };
-__device__ __forceinline__ DropSeed drop_seed(const DropP& d) {
-    DropSeed s = {0u, 0u, 0u};
-    if (d.rng) {
-        const __attribute__((address_space(1))) uint64_t* rng = (const __attribute__((address_space(1))) uint64_t*)d.rng;
-        const uint64_t seed = rng[0];
-        s.k0 = (uint32_t)seed; s.k1 = (uint32_t)(seed >> 32); s.step = (uint32_t)rng[1];
-    }
-    return s;
-}
+// keep-mask x scale of ONE element (common.h: DropSeed, drop_mult4)
 __device__ __forceinline__ float drop_mult1(const DropP& d, const DropSeed& sd, uint64_t e) {
     if (d.thresh == 0) return d.scale;
     const uint64_t grp = e >> 2;
@@ -134,8 +122,8 @@ top_fwd_kernel(const TopFwdP P) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
-        f32x4 v = {0, 0, 0, 0};
-        if (r < L) v = gld4(P.X + (tok0 + r) * 64 + c4);
+        f32x4 v = gld4(P.X + (tok0 + min(r, L - 1)) * 64 + c4);      // branch-free: rows past L re-read row L-1, zeroed
+        if (r >= L) v = f32x4{0, 0, 0, 0};
         st4(sX + r * FS + c4, v);
     }
     // weight rows of the one-row products, requested now (query, dense) and after the MFMA phase (feed-forward)
@@ -394,8 +382,9 @@ top_bwd_kernel(const TopBwdP P) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
-        tx[p] = f32x4{0, 0, 0, 0}; tk[p] = tx[p]; tv[p] = tx[p];
-        if (r < L) { tx[p] = gld4(P.X + (tok0 + r) * 64 + c4); tk[p] = gld4(P.k + (tok0 + r) * 64 + c4); tv[p] = gld4(P.v + (tok0 + r) * 64 + c4); }
+        const long et = (tok0 + min(r, L - 1)) * 64 + c4;            // branch-free: rows past L re-read row L-1, zeroed
+        tx[p] = gld4(P.X + et); tk[p] = gld4(P.k + et); tv[p] = gld4(P.v + et);
+        if (r >= L) { tx[p] = f32x4{0, 0, 0, 0}; tk[p] = tx[p]; tv[p] = tx[p]; }
     }
 
     // ---- dU = (dT2 . W2) * gelu'(u)   (one of the 256 inner units per thread)
