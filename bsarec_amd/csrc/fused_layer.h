@@ -947,6 +947,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R3_wo = KARG(FusedBwdP, wo);
     // ---- stage A3: dH = dU . W1, K split: group g owns inner units [128g, 128g+128) -> partial tiles sG / sdF
     f32x4 wO[4];
+    f32x4 pq[2], pk[2], pv[2], xa[2], xf[2];                 // stage B1's operands, prefetched below
+    float ra[2], rf[2];
     {
         f32x16 acc;
 #pragma unroll
@@ -954,6 +956,16 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         const float* sa = sdU + (wm * 32 + l31) * FU + 128 * grp + 4 * half;
         load_wT8<64>(R3_w1 + (long)(128 * grp + 64 + 4 * half) * 64 + col, wB);
         load_wT4<64>(R3_wo + (long)(32 * grp + 4 * half) * 64 + col, wO);          // dense^T half for stage B2
+        // stage B1's operands (q, k, v, xhat of both LayerNorms: 80 KB per sequence) are requested here, AFTER the weight
+        // fragments this stage waits for (loads return in issue order), and land while the MFMAs below run
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
+            const long ec = (tok0 + min(r, L - 1)) * 64 + lc;
+            pq[i] = gld4(KARG(FusedBwdP, q) + ec); pk[i] = gld4(KARG(FusedBwdP, k) + ec); pv[i] = gld4(KARG(FusedBwdP, v) + ec);
+            xa[i] = gld4(KARG(FusedBwdP, xhat_a) + ec); xf[i] = gld4(KARG(FusedBwdP, xhat_f) + ec);
+            ra[i] = gld(KARG(FusedBwdP, rstd_a) + tok0 + min(r, L - 1)); rf[i] = gld(KARG(FusedBwdP, rstd_f) + tok0 + min(r, L - 1));
+        }
         mma_w8(sa, wA, acc);                                 // chunk 0 of this group sits in wA
         mma_w8(sa + 64, wB, acc);
         float* part = grp == 0 ? sG : sdF;
@@ -986,19 +998,12 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     {
         const f32x4 ga = gld4(R4_a_g + lc), gf = gld4(R4_f_g + lc);
         f32x4 sga = {0, 0, 0, 0}, sba = sga, sgf = sga, sbf = sga;
-        f32x4 xa[2], xf[2];
-        float ra[2], rf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * i + lr;
-            const long e = (tok0 + r) * 64 + lc;
-            const bool okl = r < L;                         // branch-free loads: rows past L re-read row L-1, then zeroed
-            const long ec = (tok0 + min(r, L - 1)) * 64 + lc;
             const f32x4 z4 = {0, 0, 0, 0};
-            f32x4 q4 = gld4(R4_q + ec), k4 = gld4(R4_k + ec), v4 = gld4(R4_v + ec);
-            xa[i] = gld4(R4_xhat_a + ec); xf[i] = gld4(R4_xhat_f + ec);
-            ra[i] = gld(R4_rstd_a + tok0 + min(r, L - 1)); rf[i] = gld(R4_rstd_f + tok0 + min(r, L - 1));
-            if (!okl) { q4 = z4; k4 = z4; v4 = z4; xa[i] = z4; xf[i] = z4; ra[i] = 0.f; rf[i] = 0.f; }
+            f32x4 q4 = pq[i], k4 = pk[i], v4 = pv[i];          // prefetched in stage A3 (rows past L hold row L-1: zeroed here)
+            if (r >= L) { q4 = z4; k4 = z4; v4 = z4; xa[i] = z4; xf[i] = z4; ra[i] = 0.f; rf[i] = 0.f; }
             st4(sQ + r * FS + lc, q4); st4(sK + r * FS + lc, k4); st4(sV + r * FS + lc, v4);
         }
 #pragma unroll
