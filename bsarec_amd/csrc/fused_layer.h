@@ -10,7 +10,8 @@
 //   * attention is computed transposed (S^T = K.Q^T: lane = query, registers = keys) so the softmax is a
 //     reduction over registers plus one cross-half shuffle, and P^T is consumed in place as the B operand
 //     of ctx^T = V^T.P^T (an accumulator tile is a valid B operand of a product that sums over its rows).
-// 4 waves (2 x 2 over a 64-token x 64-feature tile), 1 workgroup per CU (~127 KB LDS).
+// 8 waves = 2 groups of 4 (each 2 x 2 over a 64-token x 64-feature tile), two waves per SIMD, 1 workgroup per CU
+// (~145 KB LDS forward, ~159 KB backward).
 #pragma once
 #include "common.h"
 #include "kernels.h"
@@ -75,19 +76,6 @@ __device__ __forceinline__ int gldi(const int* p) { return *(const AS_GLOBAL int
 
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
-// acc += A(rows from LDS) . W^T(rows from global), K = 8*NKB.  sa / gw already point at this lane's row + 4*half.
-template <int NKB>
-__device__ __forceinline__ void mma_rows_w(const float* __restrict__ sa, const float* __restrict__ gw, f32x16& acc) {
-    f32x4 w[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) w[kb] = ld4(gw + 8 * kb);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        const f32x4 a = ld4(sa + 8 * kb);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
-    }
-}
 
 
 // ---- pruned DFT with a per-workgroup twiddle table tab[k][t] = (cos, sin)(2 pi k t / L), k < cb, t < 64
@@ -169,16 +157,6 @@ __device__ __forceinline__ void mma_w8(const float* __restrict__ sa, const f32x4
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
         const f32x4 a = ld4(sa + 8 * kb);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
-    }
-}
-// same, with erf-GELU applied to the A operand as it is read (dense_2 consumes gelu(u); u itself is what is stored)
-__device__ __forceinline__ void mma_w8_gelu(const float* __restrict__ sa, const f32x4 (&w)[8], f32x16& acc) {
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        f32x4 a = ld4(sa + 8 * kb);
-        a.x = gelu_f(a.x); a.y = gelu_f(a.y); a.z = gelu_f(a.z); a.w = gelu_f(a.w);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
     }
@@ -748,20 +726,6 @@ struct FusedBwdP {
     float* e_dz; const float *e_xhat, *e_rstd, *e_g; float *e_pg, *e_pb; DropP e_drop;
 };
 
-template <int NKB, int LDW>
-__device__ __forceinline__ void mma_rows_wT(const float* __restrict__ sa, const float* __restrict__ gw, f32x16& acc) {
-    float w[NKB][4];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) w[kb][s] = gw[(8 * kb + s) * LDW];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        const f32x4 a = ld4(sa + 8 * kb);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
-    }
-}
 
 // column sums held per lane (over this thread's rows) -> [64] partial of the sequence, via LDS scratch [rows][64]
 __device__ __forceinline__ void seq_partial_64(const f32x4& v, float* __restrict__ red, float* __restrict__ dst, float scale_by = 1.f,
