@@ -207,3 +207,43 @@ def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
     finally:
         lib.bsarec_set_fused(1)
         lib.bsarec_set_prune_top(1)
+
+
+@pytest.mark.parametrize("layers,prune", [(3, 1), (3, 0), (1, 1)])
+def test_fused_path_other_depths_vs_oracle(layers, prune):
+    """Depths other than the benchmark's 2 on the fused kernels: with 3 layers the one-row top block hands its weight-gradient
+    problems to block 1's launch and block 0 gets a launch of its own; with 1 layer the top block is also the embedding's
+    consumer, so the loss path keeps the full kernels.  Loss, last-position output and every gradient vs the oracle
+    (dropout on, shared Philox masks)."""
+    from oracle import bsarec_oracle as O
+    from bsarec_amd import _lib as Lb
+    lib = Lb.load()
+    lib.bsarec_set_prune_top(prune)
+    try:
+        B, L = 21, 50
+        cfg = O.Config(item_size=151, hidden_size=64, max_seq_length=L, num_hidden_layers=layers, num_attention_heads=2,
+                       c=5, alpha=0.7, hidden_dropout_prob=0.3, attention_probs_dropout_prob=0.2)
+        params = O.init_params(cfg, seed=layers)
+        rng = np.random.default_rng(layers)
+        for k in params:
+            if k.endswith(".bias"):
+                params[k] = (rng.standard_normal(params[k].shape) * 0.05).astype(np.float32)
+        ids = np.zeros((B, L), dtype=np.int64)
+        for b in range(B):
+            n = int(rng.integers(0, L + 1))
+            if n:
+                ids[b, L - n:] = rng.integers(1, 151, size=n)
+        ans = rng.integers(1, 151, size=B).astype(np.int64)
+        model = build_model(cfg, params)
+        model.train()
+        model.set_seed(31)
+        loss = model.calculate_loss(torch.from_numpy(ids).cuda(), torch.from_numpy(ans).cuda(), None, None, None)
+        loss.backward()
+        oloss, _, G, outs = O.loss_and_grads(params, cfg, ids, ans, O.DropoutSpec(True, 31, 1))
+        plan = model._plan(B)
+        g = plan.view(Lb.BUF_LAYER_OUT, layers, (B, L, 64)).cpu().numpy()
+        assert rel_l2(g[:, -1], outs[layers][:, -1]) <= 2e-5
+        assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
+        check_grads(model, G, tol=2e-4)
+    finally:
+        lib.bsarec_set_prune_top(1)
