@@ -85,6 +85,12 @@ def main():
     ap.add_argument("--dp", action="store_true", help="take the data-parallel step (RCCL all-reduce) even with one rank")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): everything else a library prints there -- RCCL's version banner at
+    # communicator creation, for one -- is sent to stderr by pointing fd 1 at fd 2 for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -293,7 +299,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
     if pg is not None:
         torch.distributed.destroy_process_group()
 
