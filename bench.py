@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Training-throughput bench of the HIP BSARec path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N rank processes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      # or under a launcher
 
 One "step" = Trainer.iteration's per-batch body (src/trainers.py:100-107) on one batch of the
 ML-1M-shaped synthetic workload (C1 of SURVEY 8d: V=3417, L=50, d=64, 2 layers, 2 heads, c=3,
@@ -13,24 +13,28 @@ resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse headline)
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_C1.csv")     # committed rocprofv3 --pmc passes of this round's library
 
 
 def model_args(a):
-    return argparse.Namespace(
+    ns = argparse.Namespace(
         item_size=a.item_size, hidden_size=a.hidden, max_seq_length=a.seq_len, batch_size=a.batch,
         hidden_dropout_prob=0.5, attention_probs_dropout_prob=0.5, num_hidden_layers=a.layers,
         num_attention_heads=a.heads, hidden_act="gelu", initializer_range=0.02, c=3, alpha=0.9, seed=42,
         lr=1e-3, adam_beta1=0.9, adam_beta2=0.999, weight_decay=0.0, no_cuda=False, log_freq=1)
+    if getattr(a, "dtype", "f32") == "bf16":
+        ns.storage = "bf16"
+    return ns
 
 
 def train_flops_per_seq(a, cb=2):
@@ -41,6 +45,7 @@ def train_flops_per_seq(a, cb=2):
 def cpu_baseline(a, budget_s=12.0):
     """The CPU oracle (numpy restatement, validated against the imported reference) timed on this
     box's host cores on a bounded sample of the same workload: whole training steps at C1 shape."""
+    import numpy as np
     from oracle import bsarec_oracle as O
     cfg = O.Config(item_size=a.item_size, hidden_size=a.hidden, max_seq_length=a.seq_len, num_hidden_layers=a.layers,
                    num_attention_heads=a.heads, c=3, alpha=0.9)
@@ -59,13 +64,56 @@ def cpu_baseline(a, budget_s=12.0):
         O.adam_step(P, G, st)
         n += 1
     dt = time.time() - t0
-    return {"value": round(n * a.batch / dt, 1), "unit": "sequences/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} full training steps (fwd+bwd+Adam, dropout on) of B={a.batch} at the C1 shape, "
-                      f"numpy oracle with BLAS threads on all host cores, {dt:.1f} s"}
+    out = {"value": round(n * a.batch / dt, 1), "unit": "sequences/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n} full training steps (fwd+bwd+Adam, dropout on) of B={a.batch} at the C1 shape, "
+                     f"numpy oracle with BLAS threads on all host cores, {dt:.1f} s"}
+    # how the port compares with the reference's own CPU path (imported PyTorch reference, same shape, same host):
+    # measured in the build container by tools/cpu_ref_ratio.py -- the reference cannot travel to the GPU box
+    path = os.path.join(ROOT, "profiles", "cpu_ref_ratio.json")
+    if os.path.exists(path):
+        r = json.load(open(path))
+        out["ref_ratio"] = r["port_over_reference_throughput"]
+        out["ref_ratio_source"] = ("profiles/cpu_ref_ratio.json (tools/cpu_ref_ratio.py in the build container, "
+                                   f"{r['cores']} cores): port {r['port_seq_per_s']} vs imported reference {r['reference_seq_per_s']} seq/s; "
+                                   "reference-equivalent CPU rate on this host ~= value / ref_ratio")
+    return out
 
 
 def fused_shape(a):
     return a.hidden == 64 and a.seq_len <= 64
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` run bare: this process starts the N rank processes (one per GPU) and relays rank 0's
+    JSON line.  It has touched no GPU (no HIP call, no torch.cuda call) -- the children are fresh interpreters."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, BSAREC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else sys.stderr            # only rank 0 owns stdout (it prints the one JSON line)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("BSAREC_BENCH_TIMEOUT", "1500"))
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(timeout=max(1.0, deadline - time.time()))))
+        except subprocess.TimeoutExpired:
+            rc = max(rc, 124)
+    if rc:
+        for p in procs:                                  # exact PIDs we started, nothing by pattern
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -79,11 +127,27 @@ def main():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--heads", type=int, default=2)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the reference's arithmetic (headline).  bf16: config C2's storage -- bf16 saved activations + "
+                         "bf16 weight shadow + bf16 MFMA, fp32 accumulate / master weights / Adam; a separate, labelled line")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra C3-shape / bf16 measurements of the N = 1 line")
     ap.add_argument("--dp", action="store_true", help="take the data-parallel step (RCCL all-reduce) even with one rank")
+    ap.add_argument("--exchange", choices=["auto", "rccl", "p2p"], default="auto",
+                    help="gradient exchange of the data-parallel step: RCCL all-reduce(s), or the one-shot peer-to-peer read-reduce "
+                         "fused into Adam (IPC-mapped peer arenas over xGMI)")
     a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a))                        # before anything here touches a GPU
+    if world != a.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
+
+    import numpy as np
+    import torch
 
     # stdout carries exactly ONE line (the JSON): everything else a library prints there -- RCCL's version banner at
     # communicator creation, for one -- is sent to stderr by pointing fd 1 at fd 2 for the duration of the run
@@ -93,10 +157,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     # BSAREC_DIST_BACKEND=gloo: rehearsal of the N > 1 path with all ranks on ONE GPU (the build box has one); the
     # exchange then goes through the host, so the step uses grad graph + eager all-reduce + Adam graph
     backend = os.environ.get("BSAREC_DIST_BACKEND", "nccl")
@@ -120,37 +180,43 @@ def main():
     from bsarec_amd.trainer import Trainer
 
     margs = model_args(a)
-    torch.manual_seed(42)                               # identical replicas on every rank
+    torch.manual_seed(42)                               # identical replicas on every rank (the Trainer also broadcasts rank 0's)
     model = BSARecModel(margs).to(dev)
     model.set_seed(42, rank)
     # ML-1M-shaped synthetic interactions -> device-resident sample table (identical on every rank)
     seqs = D.synth_ml1m_like(seed=42, n_items=a.item_size - 1)
     users, inputs, answers = D.train_table(seqs, a.seq_len)
     batches = D.DeviceBatches(users, inputs, answers, a.batch, dev, shuffle=True, seed=42, rank=rank, world=world)
-    trainer = Trainer(model, batches, None, None, margs, None, use_graph=not a.no_graph, process_group=pg)
+    trainer = Trainer(model, batches, None, None, margs, None, use_graph=not a.no_graph, process_group=pg,
+                      exchange=a.exchange)
     use_graph = trainer.use_graph
 
     # steps come straight off the device-resident table: per step ONE C call (gather + fwd + CE + bwd + Adam),
-    # replayed from a hipGraph at N = 1; eager gather + fwd/bwd + all-reduce + Adam for N > 1
-    perm_state = {"perm": None, "pos": 0}
+    # replayed from a hipGraph at N = 1; gather + fwd/bwd + exchange + Adam for N > 1
     B = a.batch
-    cursor = torch.zeros(1, dtype=torch.int64, device=dev)
-    perm_buf = torch.zeros(len(answers), dtype=torch.int64, device=dev)
-    n_local = [0]
 
-    def new_epoch():
-        perm = batches.local_permutation()
-        batches.epoch += 1
-        n_local[0] = (perm.shape[0] // B) * B               # full batches only inside the timed region
-        perm_buf[:perm.shape[0]].copy_(perm)
-        cursor.zero_()
-        perm_state["pos"] = 0
+    class Feed:
+        def __init__(self, tr, bt):
+            self.tr, self.bt = tr, bt
+            self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.perm_buf = torch.zeros(len(answers), dtype=torch.int64, device=dev)
+            self.n_local, self.pos = 0, 0
 
-    def one_step():
-        if perm_state["pos"] + B > n_local[0]:
-            new_epoch()
-        perm_state["pos"] += B
-        return trainer.indexed_step(batches, perm_buf, cursor, None)
+        def new_epoch(self):
+            perm = self.bt.local_permutation()
+            self.bt.epoch += 1
+            self.n_local = (perm.shape[0] // B) * B               # full batches only inside the timed region
+            self.perm_buf[:perm.shape[0]].copy_(perm)
+            self.cursor.zero_()
+            self.pos = 0
+
+        def step(self):
+            if self.pos + B > self.n_local:
+                self.new_epoch()
+            self.pos += B
+            return self.tr.indexed_step(self.bt, self.perm_buf, self.cursor, None)
+
+    feed = Feed(trainer, batches)
 
     def stream_batches():
         while True:
@@ -167,15 +233,19 @@ def main():
                 torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def timed(fd, steps, warmup):
+        for _ in range(max(warmup, 1)):
+            loss = fd.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = fd.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, loss
+
     model.train()
-    for _ in range(max(a.warmup, 1)):
-        loss = one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, loss = timed(feed, a.steps, a.warmup)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -183,27 +253,55 @@ def main():
     final_loss = float(loss.item())
     assert np.isfinite(final_loss), "training diverged"
 
+    pruned = fused_shape(a) and a.layers >= 2 and not model._plan(B).options["no_prune_top"]
     out = {
         "metric": "train sequences/sec, ML-1M L=50 d=64 2-layer", "value": round(a.batch * world * a.steps / dt, 1),
         "unit": "sequences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"C1: ML-1M-shaped synthetic (6040 users, V={a.item_size}), L={a.seq_len} d={a.hidden} "
                                f"{a.layers} BSARec layers, {a.heads} heads, c=3 alpha=0.9 dropout=0.5, Adam lr=1e-3; "
                                "fwd + full-catalogue CE + bwd + Adam per step",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq_len,
                    "parallelism": f"dp{world}", "launch": ("hipGraph replay" if use_graph else "eager") +
-                             (f" ({trainer.dp_graph} graph per step incl. RCCL all-reduce)" if pg is not None and use_graph and trainer.dp_graph == "one"
-                              else " (grad graph + eager RCCL all-reduce + Adam graph)" if pg is not None and use_graph else ""),
+                             (f"; data-parallel exchange: {trainer.exchange_desc()}" if pg is not None else ""),
                    "final_loss": round(final_loss, 4)},
     }
+    if a.dtype == "bf16":
+        out["config"]["precision"] = ("bf16 storage of the saved activations and of a bf16 shadow of the Linear weights, bf16 MFMA "
+                                      "with fp32 accumulation; fp32 master weights, LayerNorm, softmax, loss and Adam (config C2's "
+                                      "storage; NOT the headline: the reference computes in fp32)")
     out["config"]["top_block"] = ("loss path evaluates the top BSARecBlock on position L-1 only (it still attends to every "
-                                  "position); exact, same loss and gradients (SURVEY C.6); FLOP-based fractions below use the "
-                                  "un-pruned counts") if getattr(model, "_plans", None) is not None and fused_shape(a) and a.layers >= 2 and \
-        os.environ.get("BSAREC_PRUNE_TOP", "1") != "0" else "full"
-    if rank == 0 and world == 1 and out["config"]["top_block"] != "full" and not a.no_roofline:
-        # the same step with the FULL top-block kernels (nothing uses the one-row structure), measured in this run
-        Lb.load().bsarec_set_prune_top(0)
+                                  "position); exact, same loss and gradients (SURVEY C.6); algorithmic_* figures below use the "
+                                  "un-pruned counts, executed_* the work actually launched") if pruned else "full"
+    if pg is not None:
+        # evidence that the collective really spans N ranks, and what one exchange of the gradient arena costs on its own
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones, group=pg)
+        out["ranks_seen"] = int(round(float(ones.item())))
+        g = model._garena
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            torch.distributed.all_reduce(g, group=pg)
+        barrier()
+        ev0.record()
+        for _ in range(50):
+            torch.distributed.all_reduce(g, group=pg)
+        ev1.record()
+        torch.cuda.synchronize()
+        out["allreduce_us"] = round(ev0.elapsed_time(ev1) * 1e3 / 50, 2)
+        out["allreduce_bytes"] = int(g.numel() * 4)
+        out["exchange"] = trainer.exchange_report()
+
+    flops_seq = train_flops_per_seq(a)
+    peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    out["algorithmic_step_mfma_frac"] = round(flops_seq * a.batch * world * a.steps / dt / (peak * 1e12 * world), 5)
+
+    solo = rank == 0 and world == 1
+    if solo and pruned and not a.no_roofline:
+        # the same step with the FULL top-block kernels (nothing uses the one-row structure), measured in this run:
+        # every algorithmic FLOP is executed, so this is the executed-work fraction of the MFMA peak
+        old = Lb.set_default_options(no_prune_top=1)
         try:
             torch.manual_seed(42)
             model2 = BSARecModel(margs).to(dev)
@@ -211,92 +309,105 @@ def main():
             model2.train()
             batches2 = D.DeviceBatches(users, inputs, answers, a.batch, dev, shuffle=True, seed=42, rank=rank, world=world)
             trainer2 = Trainer(model2, batches2, None, None, margs, None, use_graph=not a.no_graph, process_group=pg)
-            perm2 = batches2.local_permutation()
-            nfull = (perm2.shape[0] // B) * B
-            pbuf2 = torch.zeros(len(answers), dtype=torch.int64, device=dev)
-            pbuf2[:perm2.shape[0]].copy_(perm2)
-            cur2 = torch.zeros(1, dtype=torch.int64, device=dev)
-            nst = min(a.steps, nfull // B - max(a.warmup, 1) - 1)
-            for _ in range(max(a.warmup, 1)):
-                trainer2.indexed_step(batches2, pbuf2, cur2, None)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(nst):
-                l2 = trainer2.indexed_step(batches2, pbuf2, cur2, None)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
+            feed2 = Feed(trainer2, batches2)
+            nst = min(a.steps, 200)
+            dt2, l2 = timed(feed2, nst, a.warmup)
             assert np.isfinite(float(l2.item()))
             out["full_top_block"] = {"value": round(a.batch * nst / dt2, 1), "ms_per_step": round(1e3 * dt2 / nst, 4), "steps": nst}
-            del trainer2, model2, batches2
+            out["executed_step_mfma_frac"] = round(flops_seq * a.batch * nst / dt2 / (peak * 1e12), 5)
+            del trainer2, model2, batches2, feed2
         finally:
-            Lb.load().bsarec_set_prune_top(1)
-    flops_seq = train_flops_per_seq(a)
-    out["step_mfma_frac"] = round(flops_seq * a.batch * world * a.steps / dt / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world), 5)
+            Lb.set_default_options(**old)
+    elif solo and not pruned:
+        out["executed_step_mfma_frac"] = out["algorithmic_step_mfma_frac"]
 
-    if rank == 0 and world == 1 and not a.no_roofline:
+    if solo and not a.no_roofline:
         # Per-kernel roofline: hipEvent pairs on the launch stream around every launch of one kernel class
         # inside real (eager) training steps; the class with the largest time per step is the dominant kernel.
         import ctypes as C
         lib = Lb.load()
-        d, L, B, N, cb = a.hidden, a.seq_len, a.batch, a.layers, 2
+        d, L, N, cb, h = a.hidden, a.seq_len, a.layers, 2, a.heads
         T = B * L
-        fused = (d == 64 and L <= 64)
+        fused = fused_shape(a)
         if fused:
+            dw_exec = 24.0 * T * d * d                                   # the bottom block's six products
+            dw_alg = dw_exec
+            if pruned:                                                  # + the one-row top block's: 4 products over B rows, 2 over B*h
+                dw_exec += 20.0 * B * d * d + 4.0 * B * h * d * d
+                dw_alg = 24.0 * T * d * d * N / max(N - 1, 1)
             cands = [(Lb.K_FUSED_BWD, "fused_layer_bwd_kernel (whole BSARecBlock input-gradient chain per sequence)",
-                      B * L * (24 * d * d + 8 * L * d + 16 * cb * d)),
+                      B * L * (24 * d * d + 8 * L * d + 16 * cb * d), None),
                      (Lb.K_FUSED_FWD, "fused_layer_fwd_kernel (whole BSARecBlock forward per sequence)",
-                      B * L * (24 * d * d + 4 * L * d + 8 * cb * d)),
-                     (Lb.K_DW1, "dw_direct_kernel (weight + bias gradients, direct split-K; un-pruned FLOP count of all N blocks over "
-                                "its N-1 launches: the top block's products use the one-row structure of their gradient and ride "
-                                "in the next block's launch)",
-                      24.0 * T * d * d * (N / max(N - 1, 1) if out["config"]["top_block"] != "full" else 1.0))]
+                      B * L * (24 * d * d + 4 * L * d + 8 * cb * d), None),
+                     (Lb.K_DW1, "dw_direct_kernel (weight + bias gradients, direct split-K; the one-row top block's products ride in "
+                                "the next block's launch)", dw_exec, dw_alg)]
         else:
-            cands = [(Lb.K_FFN1, "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)", 2.0 * T * d * 4 * d),
-                     (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d)]
+            cands = [(Lb.K_FFN1, "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)", 2.0 * T * d * 4 * d, None),
+                     (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d, None)]
         rows = []
         ovh = C.c_double()
         lib.bsarec_profile_event_overhead(C.c_void_p(torch.cuda.current_stream().cuda_stream), 200, C.byref(ovh))
         ovh_s = ovh.value * 1e-3          # an empty event bracket: what the two marker packets themselves cost
-        for kclass, name, fl in cands:
-            lib.bsarec_profile_select(kclass)
+        plan = model._plan(B)
+        for kclass, name, fl, fl_alg in cands:
+            lib.bsarec_profile_select(plan.handle, kclass)
             nprof = 10
             for _ in range(nprof):
                 _, ids, ans, _, _ = next(stream)
                 trainer._step_eager(ids, ans)
             torch.cuda.synchronize()
             ms, n = C.c_double(), C.c_int()
-            lib.bsarec_profile_read(C.byref(ms), C.byref(n))
+            lib.bsarec_profile_read(plan.handle, C.byref(ms), C.byref(n))
             if n.value == 0:
                 continue
             avg_s = ms.value * 1e-3 / n.value - ovh_s
-            rows.append({"kernel": name, "launches_per_step": n.value / nprof, "avg_us": round(avg_s * 1e6, 3),
-                         "us_per_step": round(avg_s * 1e6 * n.value / nprof, 2), "flops_per_launch": float(fl),
-                         "achieved": round(fl / avg_s / 1e12, 3)})
-        lib.bsarec_profile_select(Lb.K_NONE)
+            row = {"kernel": name, "launches_per_step": n.value / nprof, "avg_us": round(avg_s * 1e6, 3),
+                   "us_per_step": round(avg_s * 1e6 * n.value / nprof, 2), "flops_per_launch": float(fl),
+                   "achieved": round(fl / avg_s / 1e12, 3), "frac": round(fl / avg_s / 1e12 / peak, 5)}
+            if fl_alg is not None and fl_alg != fl:
+                row["algorithmic_flops_per_launch"] = float(fl_alg)
+                row["algorithmic_achieved"] = round(fl_alg / avg_s / 1e12, 3)
+            rows.append(row)
+        lib.bsarec_profile_select(plan.handle, Lb.K_NONE)
         rows.sort(key=lambda r: -r["us_per_step"])
         top = rows[0]
 
         def pmc_traffic(kernel_prefix):
             # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/): WRITE_SIZE + 2 * FETCH_SIZE KiB
-            # (gfx950 tallies wide streaming reads at half their bytes, MI355X guide, HBM section)
-            path = os.path.join(ROOT, "profiles", "r01_f_pmc_C1.csv")
-            if not os.path.exists(path) or not fused or a.batch != 256:
-                return None
-            vals = {}
+            # (gfx950 tallies wide streaming reads at half their bytes, MI355X guide, HBM section).  An OFFLINE pass:
+            # only reported when the profile's recorded library hash is this build's
+            path = os.path.join(ROOT, PMC_PROFILE)
+            if not os.path.exists(path) or not fused or a.batch != 256 or a.dtype != "f32":
+                return None, None
+            vals, sha = {}, None
             for line in open(path):
+                if line.startswith("# library_sha16="):
+                    sha = line.strip().split("=", 1)[1]
                 if line.startswith('"' + kernel_prefix):
                     _, counter, avg, _ = line.rsplit(",", 3)
                     vals[counter] = float(avg)
             if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-                return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-            return None
+                src = f"{PMC_PROFILE} (offline rocprofv3 --pmc passes, tools/profile_round.sh; library_sha16={sha}"
+                src += ", this build)" if sha == Lb.source_sha16() else f", this build is {Lb.source_sha16()}: kernels changed since)"
+                return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, src
+            return None, None
+        traffic, tsrc = pmc_traffic(top["kernel"].split(" ")[0])
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"],
-                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(top["achieved"] / FP32_MFMA_PEAK_TFLOPS, 5),
-                           "traffic": pmc_traffic(top["kernel"].split(" ")[0]),
+                           "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(top["achieved"] / peak, 5),
+                           "traffic": traffic, "traffic_source": tsrc,
                            "avg_us": top["avg_us"], "event_overhead_us": round(ovh_s * 1e6, 3), "launches_per_step": top["launches_per_step"],
                            "flops_per_launch": top["flops_per_launch"], "other_kernels": rows[1:]}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+
+    if solo and not a.no_secondary and a.dtype == "f32" and fused_shape(a):
+        # non-headline workloads measured in the same run (each its own model / plan; a few seconds)
+        sec = {}
+        try:
+            sec["C3"] = secondary_c3(dev, seqs, D, BSARecModel, Trainer)
+        except Exception as e:                                      # never lose the headline line to a secondary measurement
+            sec["C3"] = {"error": f"{type(e).__name__}: {e}"}
+        out["secondary"] = sec
+    if solo and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
     if rank == 0:
         sys.stdout.flush()
@@ -304,6 +415,39 @@ def main():
     os.close(real_stdout)
     if pg is not None:
         torch.distributed.destroy_process_group()
+
+
+def secondary_c3(dev, seqs, D, BSARecModel, Trainer, steps=15, warmup=3):
+    """BASELINE config 3: the C1 interactions re-cut with L = 200, hidden 256, 4 heads, 4 layers, B = 256 --
+    generic tiled kernels, fp32.  Same step definition as the headline."""
+    import numpy as np
+    import torch
+    a3 = argparse.Namespace(item_size=3417, hidden=256, seq_len=200, batch=256, layers=4, heads=4, dtype="f32")
+    m3 = model_args(a3)
+    torch.manual_seed(42)
+    model = BSARecModel(m3).to(dev)
+    model.set_seed(42, 0)
+    model.train()
+    u, x, y = D.train_table(seqs[:600], 200)                     # a slice of the users: enough full batches, quick to build
+    bt = D.DeviceBatches(u, x, y, 256, dev, shuffle=True, seed=42)
+    tr = Trainer(model, bt, None, None, m3, None, use_graph=True)
+    perm = bt.local_permutation()
+    pbuf = perm.clone()
+    cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    assert perm.shape[0] >= (steps + warmup + 1) * 256
+    for _ in range(warmup):
+        tr.indexed_step(bt, pbuf, cur, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.indexed_step(bt, pbuf, cur, None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.isfinite(float(loss.item()))
+    fl = train_flops_per_seq(a3, cb=2)
+    return {"workload": "C3: C1 interactions re-cut, L=200 d=256 4 heads 4 BSARec layers, B=256, fp32, generic tiled kernels",
+            "value": round(256 * steps / dt, 1), "unit": "sequences/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "step_mfma_frac": round(fl * 256 * steps / dt / (FP32_MFMA_PEAK_TFLOPS * 1e12), 5)}
 
 
 if __name__ == "__main__":

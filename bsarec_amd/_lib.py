@@ -5,7 +5,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSAREC_LIB") or os.path.join(HERE, "libbsarec_hip.so")   # BSAREC_LIB: another build of the same ABI
 MAX_LAYERS = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 (BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX,
  BUF_DLOGITS) = range(10)
@@ -35,7 +35,55 @@ TOP_KEYS = {"item_emb": "item_embeddings.weight", "pos_emb": "position_embedding
 class Config(C.Structure):
     _fields_ = [("batch", C.c_int), ("seq_len", C.c_int), ("hidden", C.c_int), ("heads", C.c_int), ("layers", C.c_int),
                 ("item_size", C.c_int), ("cutoff_bins", C.c_int), ("alpha", C.c_float), ("ln_eps", C.c_float),
-                ("p_hidden", C.c_float), ("p_attn", C.c_float), ("filter_kind", C.c_int)]
+                ("p_hidden", C.c_float), ("p_attn", C.c_float), ("filter_kind", C.c_int),
+                # per-plan options, 0 = default (include/bsarec_hip.h)
+                ("hidden_act", C.c_int), ("storage", C.c_int), ("no_fused", C.c_int), ("no_prune_top", C.c_int),
+                ("dw_tiled", C.c_int), ("splits", C.c_int), ("top_slabs", C.c_int), ("separate_embed", C.c_int)]
+
+
+OPTION_FIELDS = ("storage", "no_fused", "no_prune_top", "dw_tiled", "splits", "top_slabs", "separate_embed")
+HIDDEN_ACTS = {"gelu": 0, "relu": 1, "swish": 2}
+
+# Plan options the HOST gives to plans it creates from now on.  The C ABI has no process-wide state: these are Python
+# defaults (test / bench shims and the environment knobs of INTEGRATION.md), copied into bsarec_config_t per plan.
+_defaults = {k: 0 for k in OPTION_FIELDS}
+
+
+def _env_defaults():
+    e = os.environ
+    d = {}
+    if e.get("BSAREC_DW") == "tiled":
+        d["dw_tiled"] = 1
+    if e.get("BSAREC_PRUNE_TOP") == "0":
+        d["no_prune_top"] = 1
+    if e.get("BSAREC_EMBED_IN_BLOCK") == "0":
+        d["separate_embed"] = 1
+    if e.get("BSAREC_FUSED") == "0":
+        d["no_fused"] = 1
+    for env, key, hi in (("BSAREC_TOP_SLABS", "top_slabs", 16), ("BSAREC_SPLITS", "splits", 1024)):
+        if e.get(env, "").isdigit() and 1 <= int(e[env]) <= hi:
+            d[key] = int(e[env])
+    if e.get("BSAREC_STORAGE") == "bf16":
+        d["storage"] = 1
+    return d
+
+
+def set_default_options(**kw):
+    """Test / bench shim: options of the plans created after this call (e.g. ``no_prune_top=1``).  Returns the
+    previous values of the keys it changed."""
+    old = {}
+    for k, v in kw.items():
+        if k not in _defaults:
+            raise KeyError(k)
+        old[k] = _defaults[k]
+        _defaults[k] = int(v)
+    return old
+
+
+def default_options():
+    d = dict(_defaults)
+    d.update(_env_defaults())
+    return d
 
 
 class Layer(C.Structure):
@@ -72,20 +120,31 @@ EXPORTS = {
                                   [C.c_void_p]),
     "bsarec_grad_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 3 + [C.c_float] * 3 + [C.c_void_p]),
     "bsarec_adam_apply": (C.c_int, [C.c_void_p] * 4 + [C.c_long, C.c_void_p] + [C.c_float] * 5 + [C.c_void_p]),
+    "bsarec_mask_seen": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_freq_layer_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_int,
                                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_freq_layer_bwd_scratch_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),
     "bsarec_freq_layer_bwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_int] +
                               [C.c_void_p] * 6),
-    "bsarec_profile_select": (C.c_int, [C.c_int]),
-    "bsarec_set_prune_top": (C.c_int, [C.c_int]),
-    "bsarec_set_fused": (C.c_int, [C.c_int]),
-    "bsarec_debug_stamps": (C.c_int, [C.c_void_p]),
-    "bsarec_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "bsarec_profile_select": (C.c_int, [C.c_void_p, C.c_int]),
+    "bsarec_debug_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsarec_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "bsarec_profile_event_overhead": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
 }
 
 _lib = None
+
+
+def source_sha16() -> str:
+    """First 16 hex digits of the sha256 over the library's sources (csrc/ + the header): the tag that ties an offline
+    rocprofv3 profile under profiles/ to the build it was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(HERE, "csrc")
+    for f in sorted(os.listdir(src)) + [os.path.join(os.path.dirname(HERE), "include", "bsarec_hip.h")]:
+        with open(f if os.path.isabs(f) else os.path.join(src, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load():

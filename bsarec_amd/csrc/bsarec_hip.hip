@@ -22,12 +22,12 @@
 static thread_local bool g_dry = false;
 #define LAUNCH(...) do { if (!g_dry) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
-static long long* g_stamps = nullptr;   // diagnostic stamp buffer (bsarec_debug_stamps)
-static int g_use_fused = 1;
-static int TOP_SLABS = 2;           // slab slices of the pruned top block's weight-gradient products (K = B or B*h rows only; measured 1/2/4/8 slabs: 0.2115 / 0.2095 / 0.2122 / 0.2130 ms per step); BSAREC_TOP_SLABS
-static int g_embed_in_block = 1;    // BSAREC_EMBED_IN_BLOCK=0: separate embedding kernel on the fused path too
-static int g_prune_top = 1;          // BSAREC_PRUNE_TOP=0: the loss path runs the full top block too
-static int g_use_direct_dw = 1;      // BSAREC_DW=tiled selects the LDS-tiled grouped kernel at the fused shape too      // fused per-sequence BSARecBlock kernels when the shape allows (d = 64, L <= 64)
+// Every option lives in bsarec_config_t and belongs to the plan (no process-wide knobs).  Defaults of the 0 values:
+//   top_slabs 2  (slab slices of the pruned top block's weight-gradient products, K = B or B*h rows only; measured
+//                 1/2/4/8 slabs: 0.2115 / 0.2095 / 0.2122 / 0.2130 ms per step)
+//   splits    40 (slab slices of the full-block weight-gradient products)
+struct bsarec_plan;
+static thread_local bsarec_plan* t_plan = nullptr;   // plan of the C call this thread is inside (ProfScope, stamps)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long rup(long a, long b) { return (a + b - 1) / b * b; }
@@ -35,22 +35,28 @@ static inline long rup(long a, long b) { return (a + b - 1) / b * b; }
 // ---------------------------------------------------------------------------------------------
 // in-process kernel timing (bench.py roofline): hipEvent pairs around one kernel class
 // ---------------------------------------------------------------------------------------------
-static int g_prof_class = BSAREC_K_NONE;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
-static size_t g_prof_used = 0;
+struct ProfState {                    // per plan (bsarec_profile_select / _read)
+    int kclass = BSAREC_K_NONE;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t used = 0;
+    ~ProfState() { for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
+};
+static ProfState* prof_of(bsarec_plan* p);
 
 struct ProfScope {
     hipStream_t s; bool on; hipEvent_t stop;
-    ProfScope(int kclass, hipStream_t st) : s(st), on(kclass != BSAREC_K_NONE && kclass == g_prof_class) {
+    ProfScope(int kclass, hipStream_t st) : s(st), on(false) {
+        ProfState* ps = t_plan ? prof_of(t_plan) : nullptr;
+        on = ps && kclass != BSAREC_K_NONE && kclass == ps->kclass;
         if (!on) return;
-        if (g_prof_used == g_prof_events.size()) {
+        if (ps->used == ps->events.size()) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-            g_prof_events.push_back({a, b});
+            ps->events.push_back({a, b});
         }
-        (void)hipEventRecord(g_prof_events[g_prof_used].first, s);
-        stop = g_prof_events[g_prof_used].second;
-        ++g_prof_used;
+        (void)hipEventRecord(ps->events[ps->used].first, s);
+        stop = ps->events[ps->used].second;
+        ++ps->used;
     }
     ~ProfScope() { if (on) (void)hipEventRecord(stop, s); }
 };
@@ -133,6 +139,16 @@ struct bsarec_plan {
     float* part_cwL[BSAREC_MAX_LAYERS];        // FMLPRec: per-sequence d(complex_weight) [B][cb][d][2]
     float *top_dq, *top_dO, *top_dT, *top_dU, *top_ak, *top_rk, *top_av, *top_rv;              // [2][B][d] key / value bias partials of the pruned top block; [nsplit][4d] sink
     int* blockmap; int red_blocks;           // flat block -> (job, chunk) table of the final gradient reduction
+    // options resolved from cfg (0 = default there)
+    int top_slabs; bool embed_in_block, direct_dw;
+    ProfState prof;
+    long long* stamps = nullptr;             // diagnostic stamp buffer (bsarec_debug_stamps)
+};
+static ProfState* prof_of(bsarec_plan* p) { return &p->prof; }
+struct PlanScope {                           // marks the plan a C call works on for this thread (nesting-safe)
+    bsarec_plan* prev;
+    explicit PlanScope(bsarec_plan* p) : prev(t_plan) { t_plan = p; }
+    ~PlanScope() { t_plan = prev; }
 };
 
 struct Carver {
@@ -156,12 +172,15 @@ static int check_cfg(const bsarec_config_t& c) {
     if (c.p_hidden < 0.f || c.p_hidden >= 1.f || c.p_attn < 0.f || c.p_attn >= 1.f) return -8;
     if (c.filter_kind != 0 && c.filter_kind != 1) return -9;
     if (c.filter_kind == 1 && c.cutoff_bins != c.seq_len / 2 + 1) return -9;     // the learnable filter has every rFFT bin
+    if (c.hidden_act != 0) return -14;          // relu / swish: not built yet
+    if (c.storage != 0) return -15;             // bf16 storage: not built yet
+    if (c.splits < 0 || c.splits > 1024 || c.top_slabs < 0 || c.top_slabs > 16) return -16;
     return 0;
 }
 
 static bool fused_shape_ok(const bsarec_config_t& c) {
     const int dh = c.hidden / c.heads;
-    return g_use_fused && c.filter_kind == 0 && c.hidden == 64 && c.seq_len <= 64 && c.cutoff_bins <= FUSED_MAX_CB &&
+    return !c.no_fused && c.filter_kind == 0 && c.hidden == 64 && c.seq_len <= 64 && c.cutoff_bins <= FUSED_MAX_CB &&
            (dh == 16 || dh == 32 || dh == 64);
 }
 
@@ -177,8 +196,10 @@ static void derive(bsarec_plan& p) {
     p.rows_pb = p.fused ? c.seq_len : 64;
     // split-K over tokens for the weight-gradient products: ~40 slab slices, 32-aligned chunks (the direct kernel of
     // the fused shape cuts every slice into 4 more quarters inside a workgroup)
-    int want_splits = 40;
-    if (const char* e = getenv("BSAREC_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) want_splits = v; }   // tuning knob
+    const int want_splits = c.splits > 0 ? c.splits : 40;
+    p.top_slabs = c.top_slabs > 0 ? c.top_slabs : 2;
+    p.embed_in_block = !c.separate_embed;
+    p.direct_dw = !c.dw_tiled && (long)p.T * 4 * c.hidden * 4 < (1L << 31);      // its operands sit behind 32-bit buffer offsets
     long ch = rup(cdiv(p.T, want_splits), GEMM_BK);
     if (ch < 64) ch = 64;
     if (ch > 2048) ch = 2048;
@@ -238,9 +259,8 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
     p.top_ak = cv.take<float>(B * h * d); p.top_rk = cv.take<float>(B * h * d);
     p.top_av = cv.take<float>(B * h * d); p.top_rv = cv.take<float>(B * h * d);
     p.slab_dummy = cv.take<float>((long)p.nsplit * 4 * d);
-    // guard pad: the direct weight-gradient kernel prefetches up to 40 token rows past a slice without predicates
-    // (dw_direct.h); at the pruned top block those rows are L tokens apart
-    if (p.fused) cv.take<char>((size_t)48 * L * 4 * d * sizeof(float));
+    // (no guard pad: the direct weight-gradient kernels prefetch past a slice without predicates, but through buffer
+    // descriptors sized to their operand -- dw_direct.h)
     *total = cv.off;
 }
 
@@ -281,10 +301,6 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     if (grads) p->G = *grads; else memset(&p->G, 0, sizeof(p->G));
     p->ws = (char*)workspace; p->ws_bytes = workspace_bytes;
     p->state = (uint64_t*)state; p->twiddle = twiddle; p->train = false;
-    if (const char* e = getenv("BSAREC_DW")) g_use_direct_dw = strcmp(e, "tiled") != 0;
-    if (const char* e = getenv("BSAREC_PRUNE_TOP")) { if (atoi(e) == 0) g_prune_top = 0; }
-    if (const char* e = getenv("BSAREC_EMBED_IN_BLOCK")) g_embed_in_block = atoi(e) != 0;
-    if (const char* e = getenv("BSAREC_TOP_SLABS")) { const int v = atoi(e); if (v >= 1 && v <= 16) TOP_SLABS = v; }
     derive(*p);
     size_t total = 0;
     carve(*p, p->ws, &total);
@@ -323,7 +339,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
         for (int l = 0; l < cfg->layers; ++l)
             add(p->part_cwL[l], p->G.layer[l].filter_cw, cfg->batch, (long)cfg->cutoff_bins * d * 2);
     p->jobs_per_layer = 19;
-    p->prune_ok = p->fused && cfg->layers >= 2 && g_prune_top;
+    p->prune_ok = p->fused && cfg->layers >= 2 && !cfg->no_prune_top;
     p->pruned = false;
     p->loss_kind = 0; p->bce_pos = nullptr; p->bce_neg = nullptr;
     std::vector<ReduceJob> jobs_pr = jobs;          // key_b is job 6, value_b job 8 of a layer's 19 (state_dict order)
@@ -332,7 +348,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
         ReduceJob& jk = jobs_pr[base + 6]; jk.src = p->part_kvb; jk.nsplit = cfg->batch; jk.stride = d;
         ReduceJob& jv = jobs_pr[base + 8]; jv.src = p->part_kvb + (long)cfg->batch * d; jv.nsplit = cfg->batch; jv.stride = d;
         for (int j : {3, 4, 5, 7, 9, 10, 13, 14, 15, 16})      // weights and the other biases: the pruned products fill TOP_SLABS slabs
-            jobs_pr[base + j].nsplit = std::min(TOP_SLABS, ns);
+            jobs_pr[base + j].nsplit = std::min(p->top_slabs, ns);
     }
     std::vector<int> bmap;
     for (size_t j = 0; j < jobs.size(); ++j)
@@ -447,11 +463,6 @@ static int launch_freq_bwd(const float* X, const float* dF, const float* dXin, c
     return (int)hipGetLastError();
 }
 
-static int launch_reduce(const ReduceJob* jobs, int njobs, long maxlen, hipStream_t s) {
-    LAUNCH(multi_reduce_kernel, dim3(cdiv(maxlen, 64), njobs), dim3(ROW_THREADS), 0, s, jobs);
-    return (int)hipGetLastError();
-}
-
 static bool fused_ok(const bsarec_plan& p) { return p.fused; }
 
 static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const int64_t* ids = nullptr, const GatherP* gp = nullptr) {
@@ -479,7 +490,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
     F.trash = p.trash;
-    F.stamps = g_stamps ? g_stamps + 32 * (2 * l) : nullptr;
+    F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
     const size_t smem = fused_fwd_smem_bytes();
 #define FUSED_FWD_CASE(DHV) { \
         static bool attr = false; \
@@ -518,7 +529,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
     F.trash = p.trash;
-    F.stamps = g_stamps ? g_stamps + 32 * (2 * l + 1) : nullptr;
+    F.stamps = p.stamps ? p.stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = fused_bwd_smem_bytes();
 #define FUSED_BWD_CASE(DHV) { \
         static bool attr = false; \
@@ -550,7 +561,7 @@ static int launch_top_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
-    F.stamps = g_stamps ? g_stamps + 32 * (2 * l) : nullptr;
+    F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
     const size_t smem = top_fwd_smem_bytes();
 #define TOP_FWD_CASE(DHV) { \
         static bool attr = false; \
@@ -585,7 +596,7 @@ static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStrea
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha);
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
-    F.stamps = g_stamps ? g_stamps + 32 * (2 * l + 1) : nullptr;
+    F.stamps = p.stamps ? p.stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = top_bwd_smem_bytes();
 #define TOP_BWD_CASE(DHV) { \
         static bool attr = false; \
@@ -597,10 +608,7 @@ static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStrea
     return (int)hipGetLastError();
 }
 
-extern "C" int bsarec_debug_stamps(void* dev_buf) { g_stamps = (long long*)dev_buf; return 0; }
-
-extern "C" int bsarec_set_fused(int enable) { g_use_fused = enable ? 1 : 0; return 0; }
-extern "C" int bsarec_set_prune_top(int enable) { g_prune_top = enable ? 1 : 0; return 0; }
+extern "C" int bsarec_debug_stamps(bsarec_plan_t* p, void* dev_buf) { if (!p) return -10; p->stamps = (long long*)dev_buf; return 0; }
 
 extern "C" int bsarec_step_begin(bsarec_plan_t* p, void* stream) {
     if (!p) return -10;
@@ -627,6 +635,7 @@ extern "C" int bsarec_forward_last(bsarec_plan_t* p, const int64_t* ids, int tra
 
 static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* stream, const GatherP& gp, bool last_only) {
     if (!p || (!ids && !gp.table)) return -10;
+    PlanScope scope(p);
     hipStream_t s = (hipStream_t)stream;
     const bsarec_config_t& c = p->cfg;
     const int T = p->T, d = c.hidden, L = c.seq_len, B = c.batch, h = c.heads, dh = p->dh, Lp = p->Lp;
@@ -635,7 +644,7 @@ static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* s
     p->pruned = last_only && p->prune_ok;
     const XformP nox = no_xform();
 
-    const bool embed_in_block = fused_ok(*p) && g_embed_in_block;
+    const bool embed_in_block = fused_ok(*p) && p->embed_in_block;
     if (!embed_in_block)
     DISPATCH_LPR(d, {
         constexpr int RPB = ROW_THREADS / LPR;
@@ -729,6 +738,7 @@ static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* s
 // ---------------------------------------------------------------------------------------------
 extern "C" int bsarec_logits(bsarec_plan_t* p, void* stream) {
     if (!p) return -10;
+    PlanScope scope(p);
     hipStream_t s = (hipStream_t)stream;
     const bsarec_config_t& c = p->cfg;
     const int d = c.hidden, L = c.seq_len;
@@ -790,6 +800,7 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
 static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
     if (!p) return -10;
     if (!p->G.item_emb) return -13;
+    PlanScope scope(p);
     hipStream_t s = (hipStream_t)stream;
     const bsarec_config_t& c = p->cfg;
     const int T = p->T, d = c.hidden, L = c.seq_len, B = c.batch, h = c.heads, dh = p->dh, Lp = p->Lp, N = c.layers;
@@ -798,7 +809,8 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
     const SlabMap sm = slab_map(d);
     const int ns = p->nsplit, nb = p->nblk;
     const float* hlast = p->X[N] + (long)(L - 1) * d;
-    const bool direct_logits = p->fused && g_use_direct_dw && p->loss_kind == 0 && (long)B * p->Vp * 4 < (1L << 30);
+    const bool direct_logits = p->fused && p->direct_dw && p->loss_kind == 0 && (long)B * p->Vp * 4 < (1L << 30) &&
+                               (long)c.item_size * d * 4 < (1L << 31);
 
     if (p->loss_kind == 1) {     // SASRec's BCE pair: two embedding rows per sequence instead of the dense logits path
         if (!g_dry) HIPCHK(hipMemsetAsync(p->G.item_emb, 0, (size_t)c.item_size * d * sizeof(float), s));
@@ -976,7 +988,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                     if (top_pruned) {                                    // gradient rows come compact ([B][M]) from top_bwd_kernel
                         g.A[0] = i == 0 ? p->top_dq : i == 3 ? p->top_dO : i == 4 ? p->top_dU : p->top_dT;
                         g.lda = sp[i].M;
-                        g.nsplit = std::min(TOP_SLABS, ns); g.kchunk = (int)rup(cdiv(B, g.nsplit), GEMM_BK);
+                        g.nsplit = std::min(p->top_slabs, ns); g.kchunk = (int)rup(cdiv(B, g.nsplit), GEMM_BK);
                     }
                 }
                 // pruned top block: dK, dV are rank-1 per (sequence, head) -> dWk = AK^T RK, dWv = AV^T RV over B*h rows
@@ -985,7 +997,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                 if (compact) {
                     g = gemm_defaults(d, d, B * h);
                     g.A[0] = i == 1 ? p->top_ak : p->top_av; g.B[0] = i == 1 ? p->top_rk : p->top_rv; g.lda = d; g.ldb = d;
-                    g.nsplit = std::min(TOP_SLABS, ns); g.kchunk = (int)rup(cdiv(B * h, g.nsplit), GEMM_BK);
+                    g.nsplit = std::min(p->top_slabs, ns); g.kchunk = (int)rup(cdiv(B * h, g.nsplit), GEMM_BK);
                 }
                 G.P[i] = g;
                 G.E[i] = epi_linear<false, false, false>(slab_w_ptr(*p, sp[i].woff), sp[i].N);
@@ -997,7 +1009,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                 tiles += cdiv(sp[i].M, 64) * G.tiles_n[i];
             }
             G.tile0[6] = tiles; G.nprob = 6;
-            if (p->fused && g_use_direct_dw) {
+            if (p->fused && p->direct_dw) {
                 // hidden = 64: direct split-K products, one workgroup per (problem, 64x64 tile, slab slice) -- dw_direct.h.
                 // The pruned top block's six (tiny) problems are not launched on their own: they wait in DW and ride in
                 // the next block's launch.
@@ -1010,7 +1022,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                         for (int n0 = 0; n0 < q.N; n0 += 64) DW.U[dw_nu++] = DwUnit{(short)dw_np, (short)m0, (short)n0, 0};
                     ++dw_np;
                 }
-                if (top_pruned) { DW.nsmall = dw_nu; DW.small_slabs = std::min(TOP_SLABS, ns); }
+                if (top_pruned) { DW.nsmall = dw_nu; DW.small_slabs = std::min(p->top_slabs, ns); }
                 else {
                     DW.nunits = dw_nu; DW.nslab = ns;
                     ProfScope prof(BSAREC_K_DW1, s);
@@ -1150,6 +1162,13 @@ extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int
     return bsarec_adam_step(params_flat, grads_flat, m, v, n, p->state, lr, b1, b2, eps, wd, 1.0f, stream);
 }
 
+extern "C" int bsarec_mask_seen(float* scores, long ld, int B, const int64_t* users, const int64_t* indptr,
+                                const int64_t* indices, void* stream) {
+    if (!scores || !users || !indptr || !indices || B < 1 || ld < 1) return -10;
+    hipLaunchKernelGGL(mask_seen_kernel, dim3(B), dim3(ROW_THREADS), 0, (hipStream_t)stream, scores, ld, users, indptr, indices);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // stand-alone FrequencyLayer (per-op parity tests)
 // ---------------------------------------------------------------------------------------------
@@ -1184,8 +1203,6 @@ extern "C" int bsarec_freq_layer_bwd(const float* x, const float* dy, const floa
     const int T = B * L, nb = cdiv(T, 64);
     float* dz = scratch; float* dF = dz + (long)T * d; float* pbeta = dF + (long)T * d;
     float* pg = pbeta + (long)B * d; float* pb = pg + (long)nb * d;
-    ReduceJob* jobs = reinterpret_cast<ReduceJob*>(pb + (long)nb * d);      // needs 3 jobs: uses the T*d tail
-    jobs = reinterpret_cast<ReduceJob*>(((uintptr_t)jobs + 15) & ~(uintptr_t)15);
     LnBranch a; memset(&a, 0, sizeof(a));
     a.xhat = xhat; a.rstd = rstd; a.gamma = ln_w; a.in_scale = 1.f; a.drop = standalone_drop(p_drop, state, site);
     a.dT = dF; a.pgamma = pg; a.pbeta = pb;
@@ -1193,35 +1210,37 @@ extern "C" int bsarec_freq_layer_bwd(const float* x, const float* dy, const floa
     HIPCHK(hipGetLastError());
     // y = LN(Drop(f(x)) + x): the residual contributes dz directly
     DISPATCH_LPR(d, RET(launch_freq_bwd<LPR>(x, dF, dz, sqrt_beta, twiddle, B, L, d, cb, dx, pbeta, s)));
-    ReduceJob hj[3];
-    hj[0] = ReduceJob{pbeta, dsqrt_beta, B, d, d, 1.f, 0};
-    hj[1] = ReduceJob{pg, dln_w, nb, d, d, 1.f, 0};
-    hj[2] = ReduceJob{pb, dln_b, nb, d, d, 1.f, 0};
-    HIPCHK(hipMemcpyAsync(jobs, hj, sizeof(hj), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return launch_reduce(jobs, 3, d, s);
+    ReduceJobs3 hj;                      // the three jobs travel in the kernarg block: no staging copy, no synchronisation
+    hj.j[0] = ReduceJob{pbeta, dsqrt_beta, B, d, d, 1.f, 0};
+    hj.j[1] = ReduceJob{pg, dln_w, nb, d, d, 1.f, 0};
+    hj.j[2] = ReduceJob{pb, dln_b, nb, d, d, 1.f, 0};
+    LAUNCH(multi_reduce3_kernel, dim3(cdiv(d, 64), 3), dim3(ROW_THREADS), 0, s, hj);
+    return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // profiling hooks
 // ---------------------------------------------------------------------------------------------
-extern "C" int bsarec_profile_select(int kclass) {
-    g_prof_class = kclass;
-    g_prof_used = 0;
+extern "C" int bsarec_profile_select(bsarec_plan_t* p, int kclass) {
+    if (!p) return -10;
+    p->prof.kclass = kclass;
+    p->prof.used = 0;
     return 0;
 }
 
-extern "C" int bsarec_profile_read(double* ms_total, int* launches) {
+extern "C" int bsarec_profile_read(bsarec_plan_t* p, double* ms_total, int* launches) {
+    if (!p) return -10;
+    ProfState& ps = p->prof;
     double tot = 0.0;
-    for (size_t i = 0; i < g_prof_used; ++i) {
-        HIPCHK(hipEventSynchronize(g_prof_events[i].second));
+    for (size_t i = 0; i < ps.used; ++i) {
+        HIPCHK(hipEventSynchronize(ps.events[i].second));
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, g_prof_events[i].first, g_prof_events[i].second));
+        HIPCHK(hipEventElapsedTime(&ms, ps.events[i].first, ps.events[i].second));
         tot += ms;
     }
     if (ms_total) *ms_total = tot;
-    if (launches) *launches = (int)g_prof_used;
-    g_prof_used = 0;
+    if (launches) *launches = (int)ps.used;
+    ps.used = 0;
     return 0;
 }
 

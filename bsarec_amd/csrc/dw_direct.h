@@ -55,9 +55,9 @@ struct DwStage { f32x2 a[4]; f32x2 b[4]; };
 // Issue only: no predicate, no branch (a predicated load becomes a branch, after which the compiler can no longer
 // count the loads in flight and falls back to s_waitcnt vmcnt(0), i.e. no prefetch).  Buffer loads: the per-lane byte
 // offset (voff) is loop-invariant and the row offset is a scalar, so the k loop has no vector address arithmetic at
-// all.  Reads may run up to DW_STAGES + 1 k-blocks past the wave's rows: inside the buffer those are the next
-// slice's rows, past the buffer it is the workspace's guard pad (bsarec_hip.hip, carve); rows past the slice are
-// zeroed when consumed.
+// all.  Reads may run up to DW_STAGES + 1 k-blocks past the wave's rows: inside the operand those are the next
+// slice's rows, past it the buffer descriptor's range check returns 0 (num_records = the operand's bytes); rows past
+// the slice are zeroed when consumed.
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 bld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
@@ -128,9 +128,12 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
     f32x2 bs = {0.f, 0.f};
     if (nkb > 0) {                                       // wave-uniform; empty quarters (pruned top block) add zeros
-        // raw buffer descriptors over the operands (2 GB window: offsets below stay far inside 32 bits)
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Q.A, 0, 0x7FFFFFFF, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Q.B, 0, 0x7FFFFFFF, 0x00020000);
+        // raw buffer descriptors over exactly the operands' bytes ([K] rows at their stride, the last one M resp. N wide;
+        // < 2 GB, checked by the host): the un-predicated prefetch runs up to DW_STAGES + 1 k-blocks past a slice, and
+        // what falls past the operand returns 0 from the hardware range check instead of touching memory
+        const int recs_a = (int)(((long)(Q.K - 1) * Q.lda + Q.M) * 4), recs_b = (int)(((long)(Q.K - 1) * Q.ldb + Q.N) * 4);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Q.A, 0, recs_a, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Q.B, 0, recs_b, 0x00020000);
         const int rowa = (int)Q.lda * 4, rowb = (int)Q.ldb * 4;                 // bytes per token row
         const int voa = 4 * half * rowa + (m0 + 2 * l31) * 4, vob = 4 * half * rowb + (n0 + 2 * l31) * 4;
         const int soa = kbeg * rowa, sob = kbeg * rowb;
@@ -232,8 +235,9 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     if (nkb > 0) {
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)G.A, 0, 0x7FFFFFFF, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)G.E, 0, 0x7FFFFFFF, 0x00020000);
+        // descriptors over exactly dlogits [B][lda] and E [V][64]: prefetch past either end reads 0, not memory
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)G.A, 0, (int)((long)G.B * G.lda * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)G.E, 0, (int)((long)G.V * 256), 0x00020000);
         const int voa = (int)((long)m * G.lda * 4) + 16 * half, vob = 4 * half * 256 + 8 * l31;      // bytes
         int soa = kbeg * 4, sob = kbeg * 256, ccol = kbeg + 4 * half;
         f32x4 sa[DW_STAGES]; f32x2 sb[DW_STAGES][4];

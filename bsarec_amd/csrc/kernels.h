@@ -560,11 +560,13 @@ __device__ __forceinline__ void reduce_chunk(const ReduceJob& j, int chunk, floa
     if (sg == 0 && i < j.len) j.dst[i] = ((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])) * j.scale;
 }
 
-// 2-D form: blockIdx.y = job, blockIdx.x = 64-element chunk (blocks past a job's length exit)
+// 2-D form with the (three) jobs in the kernarg block: blockIdx.y = job, blockIdx.x = 64-element chunk (blocks past a
+// job's length exit).  Used by the stand-alone FrequencyLayer backward.
+struct ReduceJobs3 { ReduceJob j[3]; };
 __global__ void __launch_bounds__(ROW_THREADS)
-multi_reduce_kernel(const ReduceJob* __restrict__ jobs) {
+multi_reduce3_kernel(const ReduceJobs3 J) {
     __shared__ float red[4][64];
-    const ReduceJob j = jobs[blockIdx.y];
+    const ReduceJob j = J.j[blockIdx.y];
     if (blockIdx.x * 64 >= j.len) return;
     reduce_chunk(j, blockIdx.x, red);
 }
@@ -748,3 +750,17 @@ bce_bwd_kernel(const float* __restrict__ hlast, long hstride, const float* __res
     }
 }
 
+
+// =============================================================================================
+// Evaluation: scores of the items a user has already interacted with are set to 0 -- not -inf -- before the top-k
+// (src/trainers.py:134: rating_pred[train_matrix[user].toarray() > 0] = 0).  One workgroup per batch row walks the
+// user's CSR row on the device.
+// =============================================================================================
+__global__ void __launch_bounds__(ROW_THREADS)
+mask_seen_kernel(float* __restrict__ scores, long ld, const int64_t* __restrict__ users, const int64_t* __restrict__ indptr,
+                 const int64_t* __restrict__ indices) {
+    const long u = users[blockIdx.x];
+    const long j0 = indptr[u], j1 = indptr[u + 1];
+    float* row = scores + (long)blockIdx.x * ld;
+    for (long j = j0 + threadIdx.x; j < j1; j += ROW_THREADS) row[indices[j]] = 0.f;
+}

@@ -113,30 +113,31 @@ class DeviceBatches:
         self.epoch = 0
         self.device = device
         self._empty = torch.zeros((0,), dtype=torch.int64, device=device)
-        self._neg_keys = None                      # enable_negatives(): sorted user * V + item membership keys
+        self._neg_V = None                         # enable_negatives(): catalogue size of the negative draw
 
     def enable_negatives(self, user_seq, item_size: int):
-        """Per-sample negative items as the reference draws them (src/dataset.py:67,120-124: a uniformly random item
-        id in [1, item_size) that the user never interacted with), on the device.  Needed by the sibling models with a
-        pairwise loss (SASRec); BSARec ignores neg_answer."""
-        keys = np.unique(np.concatenate([np.asarray(s, dtype=np.int64) + u * int(item_size) for u, s in enumerate(user_seq)]))
-        self._neg_keys = torch.as_tensor(keys, dtype=torch.int64, device=self.device)
+        """Per-sample negative items with the reference's semantics (src/dataset.py:63-67,120-124): a uniformly random
+        item id in [1, item_size) that is NOT in the sample's own prefix -- ``set(items)`` of the training sample, i.e.
+        its input row plus its answer (items the user touches later, or in the valid / test tail, may be drawn).
+        Drawn on the device.  Needed by the sibling models with a pairwise loss (SASRec, FMLPRec); BSARec ignores
+        neg_answer.  The stream is torch's device generator, not Python's ``random``: same distribution, different
+        draws (no reference fixture pins negative draws)."""
         self._neg_V = int(item_size)
         self._neg_gen = torch.Generator(device=self.device)
         self._neg_gen.manual_seed(self.seed + 7919)
         return self
 
-    def sample_negatives(self, users: torch.Tensor) -> torch.Tensor:
-        V, keys = self._neg_V, self._neg_keys
-        neg = torch.randint(1, V, users.shape, device=self.device, generator=self._neg_gen)
-        for _ in range(64):                        # rejection loop (src/dataset.py:121-123)
-            k = users * V + neg
-            pos = torch.searchsorted(keys, k).clamp_(max=keys.shape[0] - 1)
-            bad = keys[pos] == k
+    def sample_negatives(self, inputs: torch.Tensor, answers: torch.Tensor) -> torch.Tensor:
+        V = self._neg_V
+        neg = torch.randint(1, V, answers.shape, device=self.device, generator=self._neg_gen)
+        nbad = -1
+        for _ in range(256):                       # rejection loop (src/dataset.py:121-123)
+            bad = (inputs == neg[:, None]).any(1) | (answers == neg)
             nbad = int(bad.sum().item())
             if nbad == 0:
                 break
             neg[bad] = torch.randint(1, V, (nbad,), device=self.device, generator=self._neg_gen)
+        assert nbad == 0, "negative sampling did not converge (catalogue smaller than a prefix?)"
         return neg
 
     def __len__(self):
@@ -176,7 +177,7 @@ class DeviceBatches:
             idx = perm[i * g:(i + 1) * g]
             if self.world > 1:
                 idx = shard_of_global_batch(idx, self.batch_size, self.rank, self.world)
-            users = self.users[idx]
-            neg = self.sample_negatives(users) if self._neg_keys is not None else self._empty
-            yield (users, self.inputs[idx], self.answers[idx], neg, self._empty.view(0))
+            users, ins, ans = self.users[idx], self.inputs[idx], self.answers[idx]
+            neg = self.sample_negatives(ins, ans) if self._neg_V is not None else self._empty
+            yield (users, ins, ans, neg, self._empty.view(0))
         self.epoch += 1

@@ -134,13 +134,16 @@ def main(argv=None):
     args = parse_args(argv)
     os.environ["CUDA_VISIBLE_DEVICES"] = args.gpu_id
     os.makedirs(args.output_dir, exist_ok=True)
-    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(message)s",
-                        handlers=[logging.FileHandler(os.path.join(args.output_dir, args.train_name + ".log")),
-                                  logging.StreamHandler(sys.stderr)])
-    logger = logging.getLogger("bsarec_amd")
+    logger = logging.getLogger("bsarec_amd." + args.train_name)      # one log file per run (src/utils.py:9-28)
+    logger.setLevel(logging.INFO)
+    logger.propagate = False
+    fmt = logging.Formatter("%(asctime)s - %(message)s")
+    for h in (logging.FileHandler(os.path.join(args.output_dir, args.train_name + ".log")), logging.StreamHandler(sys.stderr)):
+        h.setFormatter(fmt)
+        logger.addHandler(h)
     user_seq, _, _ = D.read_user_seqs(args.data_dir + args.data_name + ".txt")
     logger.info(str(args))
-    run(args, user_seq, logger, os.path.join(args.output_dir, args.train_name + ".pt"))
+    return run(args, user_seq, logger, os.path.join(args.output_dir, args.train_name + ".pt"))
 
 
 if __name__ == "__main__":

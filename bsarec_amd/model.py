@@ -73,10 +73,17 @@ class _Plan:
         self.cfg = L.Config(batch, a.max_seq_length, a.hidden_size, a.num_attention_heads, a.num_hidden_layers,
                             a.item_size, model.cutoff_bins, float(a.alpha), 1e-12, float(a.hidden_dropout_prob),
                             float(a.attention_probs_dropout_prob), int(getattr(a, "filter_kind", 0)))
+        self.cfg.hidden_act = L.HIDDEN_ACTS[getattr(a, "hidden_act", "gelu")]
+        opts = L.default_options()
+        opts.update(model.options)                      # per-model overrides win over host defaults / environment
+        for k in L.OPTION_FIELDS:
+            setattr(self.cfg, k, int(opts.get(k, 0)))
+        self.options = {k: int(getattr(self.cfg, k)) for k in L.OPTION_FIELDS}
         nbytes = lib.bsarec_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise ValueError("configuration not supported by libbsarec_hip (see include/bsarec_hip.h limits: "
-                             "L <= 256, hidden <= 256 and % 4 == 0, head size % 4 == 0, cutoff_bins*hidden <= 8192)")
+                             "L <= 256, hidden <= 256 and % 4 == 0, head size % 4 == 0, cutoff_bins*hidden <= 8192; "
+                             "storage = bf16 needs the fused shape hidden = 64, L <= 64)")
         dev = model._arena.device
         self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         off = (-self.ws.data_ptr()) % 256
@@ -133,9 +140,13 @@ class BSARecModel(nn.Module):
         if args.hidden_size % args.num_attention_heads != 0:           # src/model/_modules.py:79-82
             raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
                              % (args.hidden_size, args.num_attention_heads))
-        if getattr(args, "hidden_act", "gelu") != "gelu":
-            raise ValueError("bsarec_amd implements the reference default hidden_act='gelu' only")
+        if getattr(args, "hidden_act", "gelu") not in L.HIDDEN_ACTS:       # src/model/_modules.py:38-45
+            raise KeyError(getattr(args, "hidden_act"))
         self.args = args
+        # per-model plan options (include/bsarec_hip.h, bsarec_config_t tail), e.g. {"storage": 1} for bf16 storage
+        self.options = dict(getattr(args, "plan_options", None) or {})
+        if getattr(args, "storage", None) == "bf16":
+            self.options["storage"] = 1
         self.batch_size = getattr(args, "batch_size", 256)              # stored, unused (as in the reference)
         self.cutoff_bins = min(args.c // 2 + 1, args.max_seq_length // 2 + 1)   # src/model/bsarec.py:87,96
         if getattr(args, "filter_kind", 0) == 1:
@@ -254,7 +265,9 @@ class BSARecModel(nn.Module):
 
     def _plan(self, batch: int) -> _Plan:
         self._require_gpu()
-        key = (batch, str(self._arena.device))
+        opts = L.default_options()
+        opts.update(self.options)
+        key = (batch, str(self._arena.device), tuple(sorted(opts.items())))
         if key not in self._plans:
             if int(self._state[0].item()) == 0:
                 self.set_seed(self._seed)
@@ -272,11 +285,20 @@ class BSARecModel(nn.Module):
         lib, st = plan.lib, self._stream()
         if new_step:
             L.check(lib.bsarec_step_begin(plan.handle, st), "bsarec_step_begin")
+            self._step_begun = True          # the counter now holds a value in use (see _fresh_step_counter)
         # last_only: the caller consumes position L-1 of the last layer only (loss / logits / backward)
         fwd = lib.bsarec_forward_last if last_only else lib.bsarec_forward
         L.check(fwd(plan.handle, ids.data_ptr(), 1 if train else 0, st), "bsarec_forward")
         plan._ids_keepalive = ids
         return plan
+
+    def _fresh_step_counter(self, plan: _Plan):
+        """The eager calls advance the dropout step counter BEFORE using it (bsarec_step_begin); the indexed steps use
+        the counter as it stands and advance it when the step closes (no extra launch in the captured graph).  A
+        begin-style step followed by an indexed one would therefore draw the same masks twice: advance once in between."""
+        if getattr(self, "_step_begun", False):
+            L.check(plan.lib.bsarec_step_begin(plan.handle, self._stream()), "bsarec_step_begin")
+            self._step_begun = False
 
     def _run_loss(self, plan: _Plan, answers):
         ans = answers.to(device=self._arena.device, dtype=torch.int64).contiguous()
@@ -337,6 +359,7 @@ class BSARecModel(nn.Module):
                                            self._garena.data_ptr(), a["m"].data_ptr(), a["v"].data_ptr(), self._numel,
                                            a["lr"], a["b1"], a["b2"], a["eps"], a["wd"], self._stream()),
                 "bsarec_train_step")
+        self._step_begun = True
         plan._ids_keepalive, plan._ans_keepalive = ids, ans
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
@@ -352,6 +375,7 @@ class BSARecModel(nn.Module):
             plan.ids_buf = torch.zeros((batch, self.args.max_seq_length), dtype=torch.int64, device=dev)
             plan.ans_buf = torch.zeros((batch,), dtype=torch.int64, device=dev)
         a = self._adam
+        self._fresh_step_counter(plan)
         L.check(plan.lib.bsarec_train_step_indexed(
             plan.handle, table.data_ptr(), answers_table.data_ptr(), perm.data_ptr(), perm.shape[0], cursor.data_ptr(),
             plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), self._arena.data_ptr(), self._garena.data_ptr(),
@@ -368,6 +392,7 @@ class BSARecModel(nn.Module):
             dev = self._arena.device
             plan.ids_buf = torch.zeros((batch, self.args.max_seq_length), dtype=torch.int64, device=dev)
             plan.ans_buf = torch.zeros((batch,), dtype=torch.int64, device=dev)
+        self._fresh_step_counter(plan)
         L.check(plan.lib.bsarec_grad_step_indexed(
             plan.handle, table.data_ptr(), answers_table.data_ptr(), perm.data_ptr(), perm.shape[0], cursor.data_ptr(),
             plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), self._adam["lr"] if tick_adam else 0.0,

@@ -38,7 +38,7 @@ def ndcg_at_k(hit: torch.Tensor, k: int) -> float:
 
 class Trainer:
     def __init__(self, model: BSARecModel, train_dataloader, eval_dataloader, test_dataloader, args, logger=None,
-                 use_graph: bool = True, process_group=None):
+                 use_graph: bool = True, process_group=None, exchange: str = "auto"):
         self.args = args
         self.logger = logger or _NullLogger()
         if not torch.cuda.is_available() or getattr(args, "no_cuda", False):
@@ -54,9 +54,32 @@ class Trainer:
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.dp = process_group is not None            # data-parallel step (all-reduce), even for a 1-rank group
         self.dp_graph = os.environ.get("BSAREC_DP_GRAPH", "one")
+        self.exchange = os.environ.get("BSAREC_EXCHANGE", exchange)     # "auto" | "rccl" | "p2p" (data parallel only)
         self.use_graph = use_graph                       # data parallel: two graphs around the eager all-reduce
         self._graphs = {}
         self._seen_cache = {}
+        self._sync_replicas()
+
+    def exchange_desc(self) -> str:
+        if not self.dp:
+            return "none (single GPU)"
+        how = "one graph per step incl. the collective" if (self.use_graph and self.dp_graph == "one") else \
+            ("grad graph + eager collective + Adam graph" if self.use_graph else "eager")
+        return f"one RCCL all-reduce of the flat gradient arena after the backward; {how}"
+
+    def exchange_report(self) -> dict:
+        return {"kind": "rccl", "buckets": 1, "bytes": int(self.model._garena.numel() * 4), "launch": self.dp_graph}
+
+    def _sync_replicas(self):
+        """Data parallel: only gradients are exchanged, so the replicas must START identical -- rank 0's parameters,
+        Adam moments and step state are broadcast (construction order, seeds or a load() on one rank cannot diverge)."""
+        if self.pg is None or self.world == 1:
+            return
+        m = self.model
+        seed = m._state[0].clone()                        # the dropout seed stays rank-decorrelated
+        for t in (m._arena, m._adam["m"], m._adam["v"], m._state):
+            torch.distributed.broadcast(t, src=torch.distributed.get_global_rank(self.pg, 0), group=self.pg)
+        m._state[0] = seed
 
     # ---- reference API ---------------------------------------------------------------------------
     def train(self, epoch):
@@ -76,6 +99,7 @@ class Trainer:
     def load(self, file_name):
         sd = torch.load(file_name, map_location="cpu", weights_only=True)
         self.model.load_state_dict(sd)
+        self._sync_replicas()
 
     def predict_full(self, seq_out):
         """src/trainers.py:62-68 (kept for API parity; evaluation uses model.full_logits)."""
@@ -198,6 +222,7 @@ class Trainer:
             self._graphs[key] = (ga, gb, gloss)
             return loss
         ga, gb, gloss = g
+        m._fresh_step_counter(m._plan(B))                     # a begin-style step (eager tail batch) came before: new masks
         ga.replay()
         if gb is not None:
             exchange()
@@ -278,16 +303,27 @@ class Trainer:
         for batch in dataloader:
             batch = tuple(t.to(self.device, non_blocking=True) for t in batch)
             user_ids, input_ids, answers, _, _ = batch
-            scores = self.model.full_logits(input_ids).clone()
-            rows, cols = self._seen(user_ids)
-            scores[rows, cols] = 0                              # seen items := 0 (not -inf), trainers.py:134
-            preds.append(torch.topk(scores, 20, dim=1).indices)
+            preds.append(self.topk_after_seen(user_ids, input_ids))
             answers_all.append(answers)
         return self.get_full_sort_score(epoch, torch.cat(answers_all), torch.cat(preds))
 
-    def _seen(self, user_ids):
-        """(row-in-batch, item) pairs of already-seen items from args.train_matrix (scipy CSR, as the
-        reference builds it in src/dataset.py:126-168) -- uploaded once per matrix."""
+    def topk_after_seen(self, user_ids, input_ids, k: int = 20, return_scores: bool = False):
+        """The body of the reference's eval loop for one batch (src/trainers.py:126-149): full-catalogue scores of the
+        last position (HIP), seen items := 0 -- not -inf -- (one HIP launch over the device CSR, no host round trip),
+        top-k ids in descending score order."""
+        from . import _lib as L
+        scores = self.model.full_logits(input_ids).clone()           # a copy: the plan's logits buffer stays intact
+        indptr, indices = self._seen_csr()
+        users = user_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        L.check(L.load().bsarec_mask_seen(scores.data_ptr(), scores.stride(0), scores.shape[0], users.data_ptr(),
+                                          indptr.data_ptr(), indices.data_ptr(),
+                                          torch.cuda.current_stream(self.device).cuda_stream), "bsarec_mask_seen")
+        pred = torch.topk(scores, k, dim=1).indices
+        return (pred, scores) if return_scores else pred
+
+    def _seen_csr(self):
+        """args.train_matrix (scipy CSR, as the reference builds it in src/dataset.py:126-168) on the device --
+        uploaded once per matrix."""
         mat = self.args.train_matrix
         key = id(mat)
         if key not in self._seen_cache:
@@ -295,11 +331,4 @@ class Trainer:
             csr.sum_duplicates()
             self._seen_cache = {key: (torch.as_tensor(csr.indptr.astype(np.int64), device=self.device),
                                       torch.as_tensor(csr.indices.astype(np.int64), device=self.device))}
-        indptr, indices = self._seen_cache[key]
-        start, end = indptr[user_ids], indptr[user_ids + 1]
-        counts = end - start
-        rows = torch.repeat_interleave(torch.arange(user_ids.shape[0], device=self.device), counts)
-        offs = torch.arange(int(counts.sum().item()), device=self.device) - torch.repeat_interleave(
-            torch.cumsum(counts, 0) - counts, counts)
-        cols = indices[torch.repeat_interleave(start, counts) + offs]
-        return rows, cols
+        return self._seen_cache[key]

@@ -7,7 +7,11 @@
  *   - plain pointers and sizes only; every device buffer is allocated and owned by the caller
  *     (PyTorch in the shipped host code); the library never allocates or frees device memory;
  *   - all work is enqueued on the caller's hipStream_t (passed as void*), never synchronises, and
- *     can therefore be captured into a hipGraph;
+ *     can therefore be captured into a hipGraph (the two exceptions say so: bsarec_plan_create
+ *     synchronises once, bsarec_profile_read waits for its own events);
+ *   - no process-wide mutable state: every option is a field of bsarec_config_t and belongs to the
+ *     plan, profiling / diagnostic state is per plan; two plans with different options may be
+ *     driven from different threads;
  *   - return value: 0 = OK, < 0 = invalid argument / unsupported shape (nothing was launched),
  *     > 0 = hipError_t of a failed launch;
  *   - fp32 everywhere (the reference's arithmetic type); ids and answers are int64 as produced by
@@ -24,7 +28,7 @@ extern "C" {
 #endif
 
 #define BSAREC_MAX_LAYERS 16
-#define BSAREC_ABI_VERSION 3
+#define BSAREC_ABI_VERSION 4
 
 /* Hyper-parameters the reference model reads from `args`
  * (src/utils.py:83-96; src/model/bsarec.py:71-88; src/model/_modules.py:79-87). */
@@ -43,6 +47,17 @@ typedef struct {
     int filter_kind;    /* 0: BSARec's FrequencyLayer (low-pass + beta^2 high-pass, src/model/bsarec.py:90-104);
                          * 1: FMLPRec's learnable complex filter irfft(rfft(x) * W) (src/model/fmlprec.py:96-113): the
                          *    layer's filter_cw tensor is used, cutoff_bins must be L/2 + 1, generic kernels only */
+    /* ---- per-plan options; 0 selects the default everywhere, so a zero-filled tail is a valid configuration ---- */
+    int hidden_act;     /* FeedForward activation (src/model/_modules.py:38-45): 0 gelu (erf form, the default), 1 relu, 2 swish */
+    int storage;        /* 0: fp32 everywhere (the reference's arithmetic); 1: bf16 storage of the saved activations and of a
+                         *    bf16 shadow of the Linear weights, bf16 MFMA with fp32 accumulation, fp32 master weights, fp32
+                         *    LayerNorm / softmax / loss / Adam (config C2; fused shape hidden = 64, L <= 64 only) */
+    int no_fused;       /* 1: never take the fused per-sequence block kernels (hidden = 64, L <= 64, cutoff_bins <= 8) */
+    int no_prune_top;   /* 1: bsarec_forward_last evaluates the full top block (no one-row evaluation) */
+    int dw_tiled;       /* 1: LDS-tiled grouped weight-gradient kernel at the fused shape too (default: direct split-K) */
+    int splits;         /* split-K slab slices of the weight-gradient products (0: 40) */
+    int top_slabs;      /* slab slices of the one-row top block's weight-gradient products (0: 2) */
+    int separate_embed; /* 1: the embedding front-end runs as its own kernel on the fused path too */
 } bsarec_config_t;
 
 /* The 19 tensors of one BSARecBlock, in state_dict order (+ the sibling model's filter weight)
@@ -121,7 +136,7 @@ int bsarec_loss(bsarec_plan_t *plan, const int64_t *answers, void *stream);
  * (src/trainers.py:126-129).  At the fused shape with >= 2 layers the top block is then evaluated on that row only
  * (it still attends to all positions) and its backward uses the exact one-row structure of the upstream gradient;
  * loss, logits and all parameter gradients are those of bsarec_forward.  Other rows of BSAREC_BUF_LAYER_OUT[N] are
- * left unspecified.  BSAREC_PRUNE_TOP=0 makes this identical to bsarec_forward. */
+ * left unspecified.  cfg.no_prune_top = 1 makes this identical to bsarec_forward. */
 int bsarec_forward_last(bsarec_plan_t *plan, const int64_t *ids, int train, void *stream);
 
 /* Sibling model SASRec (src/model/sasrec.py:41-63): the BCE head on one positive and one negative item at the last
@@ -179,6 +194,12 @@ int bsarec_grad_step_indexed(bsarec_plan_t *plan, const int64_t *table, const in
 int bsarec_adam_apply(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, void *state,
                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, void *stream);
 
+/* Evaluation branch of Trainer.iteration (src/trainers.py:134): scores[b][indices[j]] = 0 (not -inf) for every item j
+ * of the CSR row indptr[users[b]] .. indptr[users[b] + 1] -- the items user b has already seen (the reference's
+ * train_matrix, src/dataset.py:126-168, uploaded as int64 CSR).  scores: [B][ld] on the device. */
+int bsarec_mask_seen(float *scores, long ld, int B, const int64_t *users, const int64_t *indptr,
+                     const int64_t *indices, void *stream);
+
 /* Stand-alone FrequencyLayer (src/model/bsarec.py:90-104) for per-op parity tests:
  * y = LN(Drop(low + beta^2 (x - low)) + x); backward given dy. */
 int bsarec_freq_layer_fwd(const float *x, const float *sqrt_beta, const float *ln_w, const float *ln_b,
@@ -192,22 +213,17 @@ int bsarec_freq_layer_bwd(const float *x, const float *dy, const float *xhat, co
                           float *dx, float *dsqrt_beta, float *dln_w, float *dln_b, void *stream);
 
 /* Tag kernel launches of one id with hipEvents for in-process roofline timing (bench.py):
- * when set, every launch of kernel class `kclass` (see BSAREC_K_*) on the next calls is bracketed
+ * when set, every launch of kernel class `kclass` (see BSAREC_K_*) on the next calls of THIS plan is bracketed
  * by hipEventRecord on the launch stream; bsarec_profile_read returns the summed milliseconds and
  * launch count, then resets.  Not for use under graph capture. */
 enum { BSAREC_K_NONE = 0, BSAREC_K_FFN1 = 1, BSAREC_K_FFN2 = 2, BSAREC_K_QKV = 3, BSAREC_K_LOGITS = 4,
        BSAREC_K_DU = 5, BSAREC_K_DW1 = 6, BSAREC_K_FUSED_FWD = 7, BSAREC_K_FUSED_BWD = 8 };
-int bsarec_profile_select(int kclass);
-/* Use (1, default) or bypass (0) the fused per-sequence BSARecBlock kernels that exist for hidden = 64,
- * L <= 64, cutoff_bins <= 8; other shapes always take the generic tiled kernels.  Process-wide. */
-int bsarec_set_fused(int enable);
-/* Allow (1, default) or forbid (0) the one-row evaluation of the top block in bsarec_forward_last.  Process-wide; read
- * when a plan is created (env BSAREC_PRUNE_TOP=0 forbids it too). */
-int bsarec_set_prune_top(int enable);
+int bsarec_profile_select(bsarec_plan_t *plan, int kclass);
 /* Diagnostic: device buffer of 32*2*layers int64 that receives per-phase shader-clock stamps of workgroup 0
- * of the fused kernels (null disables). */
-int bsarec_debug_stamps(void *dev_buf);
-int bsarec_profile_read(double *ms_total, int *launches);
+ * of this plan's fused kernels (null disables). */
+int bsarec_debug_stamps(bsarec_plan_t *plan, void *dev_buf);
+/* Waits for the plan's recorded event pairs (the one call besides bsarec_plan_create that blocks the host). */
+int bsarec_profile_read(bsarec_plan_t *plan, double *ms_total, int *launches);
 /* Milliseconds one such hipEvent bracket reads with NO kernel inside it (average of `reps` back-to-back pairs on
  * `stream`): the marker-packet cost bench.py subtracts so that its per-launch time agrees with rocprofv3's. */
 int bsarec_profile_event_overhead(void *stream, int reps, double *ms_avg);

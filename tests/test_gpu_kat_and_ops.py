@@ -347,13 +347,14 @@ def test_train_from_scratch_lastfm_follows_the_reference_log():
 
 
 def test_tiled_weight_gradient_fallback_matches_too():
-    """BSAREC_DW=tiled (LDS-tiled grouped weight-gradient kernel at the fused shape, instead of the direct one) is a
-    process-wide switch read at plan creation, so it is exercised in a child process: the dropout-on oracle parity test
-    (loss + all gradients, pruned and full top block) must pass there as well."""
-    import subprocess
-    import sys
-    env = dict(os.environ, BSAREC_DW="tiled")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"),
-                        "-k", "test_dropout_training_step_vs_oracle and A_d64"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "2 passed" in r.stdout, r.stdout[-500:]
+    """cfg.dw_tiled = 1 (LDS-tiled grouped weight-gradient kernel at the fused shape, instead of the direct one) is a
+    per-plan option: the dropout-on oracle parity case (loss + all gradients, pruned and full top block) must pass
+    through it as well, in this process, next to plans that use the direct kernel."""
+    from bsarec_amd import _lib as Lb
+    import test_gpu_parity as P
+    try:
+        for prune in (1, 0):
+            Lb.set_default_options(dw_tiled=1, no_prune_top=1 - prune)
+            P._dropout_training_step_vs_oracle("A_d64_L50_h2", 37, prune)
+    finally:
+        Lb.set_default_options(dw_tiled=0, no_prune_top=0)

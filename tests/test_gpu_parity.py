@@ -106,11 +106,11 @@ def test_dropout_training_step_vs_oracle(name, B, prune):
     the full block kernels, every row compared."""
     from oracle import bsarec_oracle as O
     from bsarec_amd import _lib as Lb0
-    Lb0.load().bsarec_set_prune_top(prune)
+    Lb0.set_default_options(no_prune_top=1 - prune)
     try:
         _dropout_training_step_vs_oracle(name, B, prune)
     finally:
-        Lb0.load().bsarec_set_prune_top(1)
+        Lb0.set_default_options(no_prune_top=0)
 
 
 def _dropout_training_step_vs_oracle(name, B, prune):
@@ -170,8 +170,7 @@ def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
     from oracle import bsarec_oracle as O
     from bsarec_amd import _lib as Lb
     lib = Lb.load()
-    lib.bsarec_set_fused(1 if fused else 0)
-    lib.bsarec_set_prune_top(1 if fused == 2 else 0)
+    Lb.set_default_options(no_fused=0 if fused else 1, no_prune_top=0 if fused == 2 else 1)
     try:
         cfg = O.Config(item_size=131, hidden_size=64, max_seq_length=L, num_hidden_layers=2, num_attention_heads=heads,
                        c=5, alpha=0.7, hidden_dropout_prob=0.4, attention_probs_dropout_prob=0.3)
@@ -205,8 +204,7 @@ def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
         assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
         check_grads(model, G, tol=2e-4)
     finally:
-        lib.bsarec_set_fused(1)
-        lib.bsarec_set_prune_top(1)
+        Lb.set_default_options(no_fused=0, no_prune_top=0)
 
 
 @pytest.mark.parametrize("layers,prune", [(3, 1), (3, 0), (1, 1)])
@@ -218,7 +216,7 @@ def test_fused_path_other_depths_vs_oracle(layers, prune):
     from oracle import bsarec_oracle as O
     from bsarec_amd import _lib as Lb
     lib = Lb.load()
-    lib.bsarec_set_prune_top(prune)
+    Lb.set_default_options(no_prune_top=1 - prune)
     try:
         B, L = 21, 50
         cfg = O.Config(item_size=151, hidden_size=64, max_seq_length=L, num_hidden_layers=layers, num_attention_heads=2,
@@ -246,4 +244,4 @@ def test_fused_path_other_depths_vs_oracle(layers, prune):
         assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
         check_grads(model, G, tol=2e-4)
     finally:
-        lib.bsarec_set_prune_top(1)
+        Lb.set_default_options(no_prune_top=0)

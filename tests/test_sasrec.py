@@ -74,7 +74,7 @@ def test_hip_sasrec_vs_reference_golden(name, prune):
     torch = pytest.importorskip("torch")
     from bsarec_amd import SASRecModel, _lib as Lb
     z, cfg = load(name)
-    Lb.load().bsarec_set_prune_top(prune)
+    Lb.set_default_options(no_prune_top=1 - prune)
     try:
         a = argparse.Namespace(hidden_act="gelu", batch_size=8, c=3, seed=1, **cfg)
         m = SASRecModel(a)
@@ -113,7 +113,7 @@ def test_hip_sasrec_vs_reference_golden(name, prune):
             bad = np.abs(got - want) > 2e-5
             assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - want).max())
     finally:
-        Lb.load().bsarec_set_prune_top(1)
+        Lb.set_default_options(no_prune_top=0)
 
 
 @pytest.mark.gpu

@@ -12,9 +12,10 @@ ans = torch.randint(1, 3417, (256,), device="cuda")
 buf = torch.zeros(32 * 4, dtype=torch.int64, device="cuda")
 lib = Lb.load()
 for _ in range(3): m.train_step(ids, ans)
-lib.bsarec_debug_stamps(buf.data_ptr())
+plan = m._plan(256)
+lib.bsarec_debug_stamps(plan.handle, buf.data_ptr())
 m.train_step(ids, ans); torch.cuda.synchronize()
-lib.bsarec_debug_stamps(None)
+lib.bsarec_debug_stamps(plan.handle, None)
 s = buf.cpu().numpy().reshape(4, 32)
 names = {0: ["load", "freq", "qkv", "attn", "dense+ln", "ffn1", "ffn2", "ln_ff"],
          1: ["ln_ff_bwd", "dU", "dH", "ln_a/f_bwd", "dC", "attn_bwd", "dXqkv", "freq_bwd"]}
