@@ -95,11 +95,20 @@ class Tensors(C.Structure):
                 ("layer", Layer * MAX_LAYERS)]
 
 
+class Adam(C.Structure):
+    """bsarec_adam_t"""
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_long), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("shadow_bf16", C.c_void_p), ("shadow_from", C.c_long)]
+
+
 EXPORTS = {
     "bsarec_abi_version": (C.c_int, []),
     "bsarec_workspace_bytes": (C.c_size_t, [C.POINTER(Config)]),
     "bsarec_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config), C.POINTER(Tensors), C.POINTER(Tensors),
-                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.POINTER(Tensors), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_shadow_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsarec_buffer_is_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bsarec_plan_destroy": (None, [C.c_void_p]),
     "bsarec_buffer_offset": (C.c_long, [C.c_void_p, C.c_int, C.c_int]),
     "bsarec_step_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -110,16 +119,13 @@ EXPORTS = {
     "bsarec_loss_logsig": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_logits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "bsarec_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_float,
-                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
-    "bsarec_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "bsarec_adam_step": (C.c_int, [C.POINTER(Adam), C.c_void_p, C.c_void_p]),
+    "bsarec_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Adam), C.c_void_p]),
     "bsarec_gather_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
-    "bsarec_train_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 7 + [C.c_long] + [C.c_float] * 5 +
-                                  [C.c_void_p]),
+    "bsarec_train_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 3 + [C.POINTER(Adam), C.c_void_p]),
     "bsarec_grad_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 3 + [C.c_float] * 3 + [C.c_void_p]),
-    "bsarec_adam_apply": (C.c_int, [C.c_void_p] * 4 + [C.c_long, C.c_void_p] + [C.c_float] * 5 + [C.c_void_p]),
+    "bsarec_adam_apply": (C.c_int, [C.POINTER(Adam), C.c_void_p, C.c_void_p]),
     "bsarec_mask_seen": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_freq_layer_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_int,
                                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -110,7 +110,8 @@ struct LayerBufs {
 
 struct bsarec_plan {
     bsarec_config_t cfg;
-    bsarec_tensors_t P, G;
+    bsarec_tensors_t P, G, S;                  // parameters, gradients, bf16 shadow of the parameters (storage = 1)
+    bool bf;                                   // cfg.storage == 1
     char* ws; size_t ws_bytes;
     uint64_t* state;
     const float* twiddle;
@@ -173,7 +174,7 @@ static int check_cfg(const bsarec_config_t& c) {
     if (c.filter_kind != 0 && c.filter_kind != 1) return -9;
     if (c.filter_kind == 1 && c.cutoff_bins != c.seq_len / 2 + 1) return -9;     // the learnable filter has every rFFT bin
     if (c.hidden_act != 0) return -14;          // relu / swish: not built yet
-    if (c.storage != 0) return -15;             // bf16 storage: not built yet
+    if (c.storage < 0 || c.storage > 1) return -15;
     if (c.splits < 0 || c.splits > 1024 || c.top_slabs < 0 || c.top_slabs > 16) return -16;
     return 0;
 }
@@ -186,6 +187,7 @@ static bool fused_shape_ok(const bsarec_config_t& c) {
 
 static void derive(bsarec_plan& p) {
     const bsarec_config_t& c = p.cfg;
+    p.bf = c.storage == 1;
     p.T = c.batch * c.seq_len;
     p.Lp = (int)rup(c.seq_len, 4);
     p.Vp = (int)rup(c.item_size, 4);
@@ -198,7 +200,7 @@ static void derive(bsarec_plan& p) {
     // the fused shape cuts every slice into 4 more quarters inside a workgroup)
     const int want_splits = c.splits > 0 ? c.splits : 40;
     p.top_slabs = c.top_slabs > 0 ? c.top_slabs : 2;
-    p.embed_in_block = !c.separate_embed;
+    p.embed_in_block = !c.separate_embed || p.bf;     // bf16 storage: X[0] is written by the block kernel only
     p.direct_dw = !c.dw_tiled && (long)p.T * 4 * c.hidden * 4 < (1L << 31);      // its operands sit behind 32-bit buffer offsets
     long ch = rup(cdiv(p.T, want_splits), GEMM_BK);
     if (ch < 64) ch = 64;
@@ -268,6 +270,7 @@ extern "C" int bsarec_abi_version(void) { return BSAREC_ABI_VERSION; }
 
 extern "C" size_t bsarec_workspace_bytes(const bsarec_config_t* cfg) {
     if (!cfg || check_cfg(*cfg) != 0) return 0;
+    if (cfg->storage == 1 && !fused_shape_ok(*cfg)) return 0;       // bf16 storage exists for the fused shape class only
     bsarec_plan p;
     p.cfg = *cfg;
     derive(p);
@@ -290,15 +293,17 @@ static float* slab_w_ptr(const bsarec_plan& p, long tensor_off) { return p.slab_
 static float* slab_b_ptr(const bsarec_plan& p, long tensor_off) { return p.slab_b + tensor_off * p.nsplit; }
 
 extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cfg, const bsarec_tensors_t* params,
-                                  const bsarec_tensors_t* grads, void* workspace, size_t workspace_bytes,
-                                  void* state, const float* twiddle, void* stream) {
+                                  const bsarec_tensors_t* grads, const bsarec_tensors_t* shadow, void* workspace,
+                                  size_t workspace_bytes, void* state, const float* twiddle, void* stream) {
     if (!out || !cfg || !params || !workspace || !state || !twiddle) return -10;
     RET(check_cfg(*cfg));
+    if (cfg->storage == 1 && (!fused_shape_ok(*cfg) || !shadow)) return -15;
     if (((uintptr_t)workspace & 255) != 0) return -11;
     bsarec_plan* p = new bsarec_plan();
     p->cfg = *cfg;
     p->P = *params;
     if (grads) p->G = *grads; else memset(&p->G, 0, sizeof(p->G));
+    if (shadow) p->S = *shadow; else memset(&p->S, 0, sizeof(p->S));
     p->ws = (char*)workspace; p->ws_bytes = workspace_bytes;
     p->state = (uint64_t*)state; p->twiddle = twiddle; p->train = false;
     derive(*p);
@@ -401,6 +406,33 @@ extern "C" long bsarec_buffer_offset(const bsarec_plan_t* p, int buffer, int lay
     return (long)((const char*)ptr - p->ws);
 }
 
+extern "C" int bsarec_buffer_is_bf16(const bsarec_plan_t* p, int buffer, int layer) {
+    if (!p || !p->bf) return 0;
+    switch (buffer) {
+        case BSAREC_BUF_LAYER_OUT: return layer < p->cfg.layers ? 1 : 0;     // the last layer's output stays fp32
+        case BSAREC_BUF_HMIX: case BSAREC_BUF_PROBS: case BSAREC_BUF_CTX: return 1;
+        case BSAREC_BUF_DLAYER_IN: return 1;
+        default: return 0;
+    }
+}
+
+extern "C" int bsarec_shadow_refresh(bsarec_plan_t* p, void* stream) {
+    if (!p) return -10;
+    if (!p->bf) return 0;
+    const long d = p->cfg.hidden;
+    for (int l = 0; l < p->cfg.layers; ++l) {
+        const bsarec_layer_t& w = p->P.layer[l];
+        const bsarec_layer_t& sh = p->S.layer[l];
+        CastJobs6 J;
+        const float* src[6] = {w.query_w, w.key_w, w.value_w, w.dense_w, w.ffn1_w, w.ffn2_w};
+        float* dst[6] = {sh.query_w, sh.key_w, sh.value_w, sh.dense_w, sh.ffn1_w, sh.ffn2_w};
+        for (int i = 0; i < 6; ++i) { J.src[i] = src[i]; J.dst[i] = (unsigned short*)dst[i]; J.n4[i] = (i < 4 ? d * d : 4 * d * d) / 4; }
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(cdiv(4 * d * d / 4, ROW_THREADS), 6), dim3(ROW_THREADS), 0, (hipStream_t)stream, J);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------------------------
@@ -468,14 +500,16 @@ static bool fused_ok(const bsarec_plan& p) { return p.fused; }
 static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const int64_t* ids = nullptr, const GatherP* gp = nullptr) {
     const bsarec_config_t& c = p.cfg;
     const bsarec_layer_t& w = p.P.layer[l];
+    const bsarec_layer_t& wm = p.bf ? p.S.layer[l] : w;      // MFMA operands: bf16 shadow of the Linear weights (storage = 1)
     LayerBufs& b = p.lb[l];
     FusedFwdP F;
     memset(&F, 0, sizeof(F));
     F.X = p.X[l]; F.Xout = p.X[l + 1];
+    F.xout_f32 = (l == c.layers - 1);
     F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.f_b = w.filter_ln_b;
-    F.wq = w.query_w; F.bq = w.query_b; F.wk = w.key_w; F.bk = w.key_b; F.wv = w.value_w; F.bv = w.value_b;
-    F.wo = w.dense_w; F.bo = w.dense_b; F.a_g = w.attn_ln_w; F.a_b = w.attn_ln_b;
-    F.w1 = w.ffn1_w; F.b1 = w.ffn1_b; F.w2 = w.ffn2_w; F.b2 = w.ffn2_b; F.ff_g = w.ffn_ln_w; F.ff_b = w.ffn_ln_b;
+    F.wq = wm.query_w; F.bq = w.query_b; F.wk = wm.key_w; F.bk = w.key_b; F.wv = wm.value_w; F.bv = w.value_b;
+    F.wo = wm.dense_w; F.bo = w.dense_b; F.a_g = w.attn_ln_w; F.a_b = w.attn_ln_b;
+    F.w1 = wm.ffn1_w; F.b1 = w.ffn1_b; F.w2 = wm.ffn2_w; F.b2 = w.ffn2_b; F.ff_g = w.ffn_ln_w; F.ff_b = w.ffn_ln_b;
     F.tw = p.twiddle; F.ids32 = p.ids32;
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs; F.ctx = b.ctx;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.hmix = b.hmix; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
@@ -492,13 +526,14 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
     F.trash = p.trash;
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
     const size_t smem = fused_fwd_smem_bytes();
-#define FUSED_FWD_CASE(DHV) { \
+#define FUSED_FWD_CASE(DHV, BFV) { \
         static bool attr = false; \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV>), \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
         ProfScope prof(BSAREC_K_FUSED_FWD, s); \
-        LAUNCH(fused_layer_fwd_kernel<DHV>, dim3(c.batch), dim3(512), smem, s, F); }
-    if (p.dh == 16) FUSED_FWD_CASE(16) else if (p.dh == 32) FUSED_FWD_CASE(32) else FUSED_FWD_CASE(64)
+        LAUNCH((fused_layer_fwd_kernel<DHV, BFV>), dim3(c.batch), dim3(512), smem, s, F); }
+    if (p.bf) { if (p.dh == 16) FUSED_FWD_CASE(16, true) else if (p.dh == 32) FUSED_FWD_CASE(32, true) else FUSED_FWD_CASE(64, true) }
+    else { if (p.dh == 16) FUSED_FWD_CASE(16, false) else if (p.dh == 32) FUSED_FWD_CASE(32, false) else FUSED_FWD_CASE(64, false) }
 #undef FUSED_FWD_CASE
     return (int)hipGetLastError();
 }
@@ -506,13 +541,14 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
 static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, float* dXout, hipStream_t s, bool top) {
     const bsarec_config_t& c = p.cfg;
     const bsarec_layer_t& w = p.P.layer[l];
+    const bsarec_layer_t& wm = p.bf ? p.S.layer[l] : w;
     LayerBufs& b = p.lb[l];
     const long nb = p.nblk, d = c.hidden;
     FusedBwdP F;
     memset(&F, 0, sizeof(F));
     F.dY = dY; F.dX = dXout; F.X = p.X[l];
-    F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.wq = w.query_w; F.wk = w.key_w; F.wv = w.value_w; F.wo = w.dense_w;
-    F.a_g = w.attn_ln_w; F.w1 = w.ffn1_w; F.w2 = w.ffn2_w; F.ff_g = w.ffn_ln_w; F.tw = p.twiddle;
+    F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.wq = wm.query_w; F.wk = wm.key_w; F.wv = wm.value_w; F.wo = wm.dense_w;
+    F.a_g = w.attn_ln_w; F.w1 = wm.ffn1_w; F.w2 = wm.ffn2_w; F.ff_g = w.ffn_ln_w; F.tw = p.twiddle;
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
     if (top) { F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.loss_kind == 1 ? 1 : p.vsplit; F.dh_stride = (long)c.batch * d; }
@@ -531,13 +567,14 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.trash = p.trash;
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = fused_bwd_smem_bytes();
-#define FUSED_BWD_CASE(DHV) { \
+#define FUSED_BWD_CASE(DHV, BFV) { \
         static bool attr = false; \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV>), \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
         ProfScope prof(BSAREC_K_FUSED_BWD, s); \
-        LAUNCH(fused_layer_bwd_kernel<DHV>, dim3(c.batch), dim3(512), smem, s, F); }
-    if (p.dh == 16) FUSED_BWD_CASE(16) else if (p.dh == 32) FUSED_BWD_CASE(32) else FUSED_BWD_CASE(64)
+        LAUNCH((fused_layer_bwd_kernel<DHV, BFV>), dim3(c.batch), dim3(512), smem, s, F); }
+    if (p.bf) { if (p.dh == 16) FUSED_BWD_CASE(16, true) else if (p.dh == 32) FUSED_BWD_CASE(32, true) else FUSED_BWD_CASE(64, true) }
+    else { if (p.dh == 16) FUSED_BWD_CASE(16, false) else if (p.dh == 32) FUSED_BWD_CASE(32, false) else FUSED_BWD_CASE(64, false) }
 #undef FUSED_BWD_CASE
     return (int)hipGetLastError();
 }
@@ -557,18 +594,20 @@ static int launch_top_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs; F.ctx = b.ctx;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.hmix = b.hmix; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
     F.low = b.dsp;
+    F.wk_sh = p.S.layer[l].key_w; F.wv_sh = p.S.layer[l].value_w;
     F.L = c.seq_len; F.Lp = p.Lp; F.cb = c.cutoff_bins; F.heads = c.heads;
     F.alpha = c.alpha; F.oma = (float)(1.0 - (double)c.alpha); F.eps = c.ln_eps;
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
     const size_t smem = top_fwd_smem_bytes();
-#define TOP_FWD_CASE(DHV) { \
+#define TOP_FWD_CASE(DHV, BFV) { \
         static bool attr = false; \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(top_fwd_kernel<DHV>), \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(top_fwd_kernel<DHV, BFV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
-        LAUNCH(top_fwd_kernel<DHV>, dim3(c.batch), dim3(256), smem, s, F); }
-    if (p.dh == 16) TOP_FWD_CASE(16) else if (p.dh == 32) TOP_FWD_CASE(32) else TOP_FWD_CASE(64)
+        LAUNCH((top_fwd_kernel<DHV, BFV>), dim3(c.batch), dim3(256), smem, s, F); }
+    if (p.bf) { if (p.dh == 16) TOP_FWD_CASE(16, true) else if (p.dh == 32) TOP_FWD_CASE(32, true) else TOP_FWD_CASE(64, true) }
+    else { if (p.dh == 16) TOP_FWD_CASE(16, false) else if (p.dh == 32) TOP_FWD_CASE(32, false) else TOP_FWD_CASE(64, false) }
 #undef TOP_FWD_CASE
     return (int)hipGetLastError();
 }
@@ -598,12 +637,13 @@ static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStrea
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = top_bwd_smem_bytes();
-#define TOP_BWD_CASE(DHV) { \
+#define TOP_BWD_CASE(DHV, BFV) { \
         static bool attr = false; \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(top_bwd_kernel<DHV>), \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(top_bwd_kernel<DHV, BFV>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
-        LAUNCH(top_bwd_kernel<DHV>, dim3(c.batch), dim3(256), smem, s, F); }
-    if (p.dh == 16) TOP_BWD_CASE(16) else if (p.dh == 32) TOP_BWD_CASE(32) else TOP_BWD_CASE(64)
+        LAUNCH((top_bwd_kernel<DHV, BFV>), dim3(c.batch), dim3(256), smem, s, F); }
+    if (p.bf) { if (p.dh == 16) TOP_BWD_CASE(16, true) else if (p.dh == 32) TOP_BWD_CASE(32, true) else TOP_BWD_CASE(64, true) }
+    else { if (p.dh == 16) TOP_BWD_CASE(16, false) else if (p.dh == 32) TOP_BWD_CASE(32, false) else TOP_BWD_CASE(64, false) }
 #undef TOP_BWD_CASE
     return (int)hipGetLastError();
 }
@@ -1018,6 +1058,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                     DwProblem& q = DW.P[dw_np];
                     q.A = g.A[0]; q.B = g.B[0]; q.lda = g.lda; q.ldb = g.ldb; q.M = g.M; q.N = g.N; q.K = g.K;
                     q.kchunk = g.kchunk; q.nslab = g.nsplit; q.slab = G.E[i].C[0]; q.bslab = G.bgrad[i]; q.gelu = G.b_gelu[i];
+                    q.bf16 = p->bf ? 1 : 0;
                     for (int m0 = 0; m0 < q.M; m0 += 64)
                         for (int n0 = 0; n0 < q.N; n0 += 64) DW.U[dw_nu++] = DwUnit{(short)dw_np, (short)m0, (short)n0, 0};
                     ++dw_np;
@@ -1091,29 +1132,35 @@ static TickP make_tick(void* state, int adam, float lr, float b1, float b2, cons
     return t;
 }
 
-static int adam_launch(float* params, const float* grads, float* m, float* v, long n, void* state, float b1, float b2,
-                       float eps, float wd, float gscale, hipStream_t s) {
-    const long n4 = n / 4;
+static int adam_check(const bsarec_adam_t* a) {
+    if (!a || !a->params || !a->grads || !a->exp_avg || !a->exp_avg_sq || a->n <= 0 || (a->n & 3)) return -10;
+    if (a->shadow_bf16 && (a->shadow_from < 0 || (a->shadow_from & 3))) return -10;
+    return 0;
+}
+
+static int adam_launch(const bsarec_adam_t& a, void* state, hipStream_t s) {
+    const long n4 = a.n / 4;
     int blocks = cdiv(n4, ROW_THREADS);
     if (blocks > 2048) blocks = 2048;
-    LAUNCH(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, params, grads, m, v, n4, (const uint64_t*)state, b1, b2, eps, wd,
-           gscale);
+    LAUNCH(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, a.params, a.grads, a.exp_avg, a.exp_avg_sq, n4,
+           (const uint64_t*)state, a.beta1, a.beta2, a.eps, a.weight_decay, a.grad_scale, (unsigned short*)a.shadow_bf16,
+           a.shadow_bf16 ? a.shadow_from / 4 : n4);
     return (int)hipGetLastError();
 }
 
-extern "C" int bsarec_adam_step(float* params, const float* grads, float* m, float* v, long n, void* state, float lr,
-                                float b1, float b2, float eps, float wd, float gscale, void* stream) {
-    if (!params || !grads || !m || !v || !state || n <= 0 || (n & 3)) return -10;
+extern "C" int bsarec_adam_step(const bsarec_adam_t* a, void* state, void* stream) {
+    RET(adam_check(a));
+    if (!state) return -10;
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH(adam_tick_kernel, dim3(1), dim3(ROW_THREADS), 0, s, make_tick(state, 1, lr, b1, b2, nullptr, 0, nullptr, nullptr, 0, 0));
+    LAUNCH(adam_tick_kernel, dim3(1), dim3(ROW_THREADS), 0, s, make_tick(state, 1, a->lr, a->beta1, a->beta2, nullptr, 0, nullptr, nullptr, 0, 0));
     HIPCHK(hipGetLastError());
-    return adam_launch(params, grads, m, v, n, state, b1, b2, eps, wd, gscale, s);
+    return adam_launch(*a, state, s);
 }
 
-extern "C" int bsarec_adam_apply(float* params, const float* grads, float* m, float* v, long n, void* state, float b1,
-                                 float b2, float eps, float wd, float gscale, void* stream) {
-    if (!params || !grads || !m || !v || !state || n <= 0 || (n & 3)) return -10;
-    return adam_launch(params, grads, m, v, n, state, b1, b2, eps, wd, gscale, (hipStream_t)stream);
+extern "C" int bsarec_adam_apply(const bsarec_adam_t* a, void* state, void* stream) {
+    RET(adam_check(a));
+    if (!state) return -10;
+    return adam_launch(*a, state, (hipStream_t)stream);
 }
 
 extern "C" int bsarec_gather_batch(const int64_t* table, const int64_t* answers_table, const int64_t* perm, long n_samples,
@@ -1126,9 +1173,9 @@ extern "C" int bsarec_gather_batch(const int64_t* table, const int64_t* answers_
 
 extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table, const int64_t* answers_table,
                                          const int64_t* perm, long n_samples, void* cursor, int64_t* ids_buf,
-                                         int64_t* answers_buf, float* params_flat, const float* grads_flat, float* m,
-                                         float* v, long n, float lr, float b1, float b2, float eps, float wd, void* stream) {
-    if (!p || !params_flat || !grads_flat || !m || !v || n <= 0 || (n & 3)) return -10;
+                                         int64_t* answers_buf, const bsarec_adam_t* a, void* stream) {
+    if (!p) return -10;
+    RET(adam_check(a));
     hipStream_t s = (hipStream_t)stream;
     if (!table || !answers_table || !perm || !cursor || !ids_buf || !answers_buf) return -10;
     GatherP gp{table, answers_table, perm, n_samples, (const long long*)cursor, ids_buf, answers_buf};
@@ -1136,9 +1183,9 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
     RET(loss_impl(p, answers_buf, stream, false));
     // the extra block of the final gradient reduction closes the step: mean loss, Adam t and bias corrections, next
     // forward-step index, cursor += B
-    RET(backward_impl(p, stream, make_tick(p->state, 1, lr, b1, b2, p->loss_rows, p->cfg.batch, p->loss, cursor,
+    RET(backward_impl(p, stream, make_tick(p->state, 1, a->lr, a->beta1, a->beta2, p->loss_rows, p->cfg.batch, p->loss, cursor,
                                            p->cfg.batch, 1)));
-    return adam_launch(params_flat, grads_flat, m, v, n, p->state, b1, b2, eps, wd, 1.0f, s);
+    return adam_launch(*a, p->state, s);
 }
 
 extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, const int64_t* answers_table,
@@ -1152,14 +1199,15 @@ extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, 
     return backward_impl(p, stream, make_tick(p->state, lr > 0.f ? 1 : 0, lr, b1, b2, nullptr, 0, nullptr, cursor, p->cfg.batch, 1));
 }
 
-extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int64_t* answers, float* params_flat,
-                                 const float* grads_flat, float* m, float* v, long n, float lr, float b1, float b2,
-                                 float eps, float wd, void* stream) {
+extern "C" int bsarec_train_step(bsarec_plan_t* p, const int64_t* ids, const int64_t* answers, const bsarec_adam_t* a,
+                                 void* stream) {
+    if (!p) return -10;
+    RET(adam_check(a));
     RET(bsarec_step_begin(p, stream));
     RET(bsarec_forward_last(p, ids, 1, stream));
     RET(bsarec_loss(p, answers, stream));
     RET(bsarec_backward(p, stream));
-    return bsarec_adam_step(params_flat, grads_flat, m, v, n, p->state, lr, b1, b2, eps, wd, 1.0f, stream);
+    return bsarec_adam_step(a, p->state, stream);
 }
 
 extern "C" int bsarec_mask_seen(float* scores, long ld, int B, const int64_t* users, const int64_t* indptr,

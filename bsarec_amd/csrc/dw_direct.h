@@ -34,6 +34,8 @@ struct DwProblem {
     float* slab;                        // [nslab][M][N]
     float* bslab;                       // [nslab][M]
     int gelu;                           // erf-GELU on the activation operand while loading (dW2 = dT2^T . gelu(u))
+    int bf16;                           // both operands are bf16 tensors (cfg.storage = 1): lda / ldb still count elements; the
+                                        // products stay fp32 MFMA on the widened values (the kernel is bound by operand bytes)
 };
 
 struct DwUnit { short prob, m0, n0, pad; };
@@ -50,7 +52,10 @@ struct DwP {
 };
 
 // one k-block (8 token rows) of operand registers: lane half h holds rows 4h .. 4h+3, two columns of each operand
-struct DwStage { f32x2 a[4]; f32x2 b[4]; };
+// (bf16 operands: the two columns are one dword)
+template <bool BF> struct DwStage;
+template <> struct DwStage<false> { f32x2 a[4]; f32x2 b[4]; };
+template <> struct DwStage<true> { unsigned a[4]; unsigned b[4]; };
 
 // Issue only: no predicate, no branch (a predicated load becomes a branch, after which the compiler can no longer
 // count the loads in flight and falls back to s_waitcnt vmcnt(0), i.e. no prefetch).  Buffer loads: the per-lane byte
@@ -62,19 +67,25 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 bld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
-__device__ __forceinline__ void dw_issue(DwStage& st, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob,
+template <bool BF>
+__device__ __forceinline__ void dw_issue(DwStage<BF>& st, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob,
                                          int soa, int sob, int rowa, int rowb) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        st.a[s] = bld2(ra, voa, soa + s * rowa);
-        st.b[s] = bld2(rb, vob, sob + s * rowb);
+        if constexpr (BF) {
+            st.a[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, voa, soa + s * rowa, 0);
+            st.b[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rb, vob, sob + s * rowb, 0);
+        } else {
+            st.a[s] = bld2(ra, voa, soa + s * rowa);
+            st.b[s] = bld2(rb, vob, sob + s * rowb);
+        }
     }
 }
 
-template <bool GELU, bool MASK>
+template <bool GELU, bool MASK, bool BF>
 __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob, int soa, int sob,
                                         int rowa, int rowb, int nkb, int crow, int kend, f32x16 (&acc)[2][2], f32x2& bs) {
-    DwStage st[DW_STAGES];
+    DwStage<BF> st[DW_STAGES];
 #pragma unroll
     for (int u = 0; u < DW_STAGES; ++u) {
         dw_issue(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
@@ -83,10 +94,12 @@ __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buff
     for (int kb = 0; kb < nkb; kb += DW_STAGES) {       // nkb is a multiple of DW_STAGES (rows past kend count as zero)
 #pragma unroll
         for (int u = 0; u < DW_STAGES; ++u) {
-            DwStage& cur = st[u];
+            DwStage<BF>& cur = st[u];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                f32x2 a = cur.a[s], b = cur.b[s];
+                f32x2 a, b;
+                if constexpr (BF) { a = f32x2{bf_lo(cur.a[s]), bf_hi(cur.a[s])}; b = f32x2{bf_lo(cur.b[s]), bf_hi(cur.b[s])}; }
+                else { a = cur.a[s]; b = cur.b[s]; }
                 if (MASK) {
                     const bool ok = crow + s < kend;
                     a.x = ok ? a.x : 0.f; a.y = ok ? a.y : 0.f; b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
@@ -131,21 +144,25 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
         // raw buffer descriptors over exactly the operands' bytes ([K] rows at their stride, the last one M resp. N wide;
         // < 2 GB, checked by the host): the un-predicated prefetch runs up to DW_STAGES + 1 k-blocks past a slice, and
         // what falls past the operand returns 0 from the hardware range check instead of touching memory
-        const int recs_a = (int)(((long)(Q.K - 1) * Q.lda + Q.M) * 4), recs_b = (int)(((long)(Q.K - 1) * Q.ldb + Q.N) * 4);
+        const int esz = Q.bf16 ? 2 : 4;                                         // bytes per operand element
+        const int recs_a = (int)(((long)(Q.K - 1) * Q.lda + Q.M) * esz), recs_b = (int)(((long)(Q.K - 1) * Q.ldb + Q.N) * esz);
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Q.A, 0, recs_a, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Q.B, 0, recs_b, 0x00020000);
-        const int rowa = (int)Q.lda * 4, rowb = (int)Q.ldb * 4;                 // bytes per token row
-        const int voa = 4 * half * rowa + (m0 + 2 * l31) * 4, vob = 4 * half * rowb + (n0 + 2 * l31) * 4;
+        const int rowa = (int)Q.lda * esz, rowb = (int)Q.ldb * esz;             // bytes per token row
+        const int voa = 4 * half * rowa + (m0 + 2 * l31) * esz, vob = 4 * half * rowb + (n0 + 2 * l31) * esz;
         const int soa = kbeg * rowa, sob = kbeg * rowb;
         const int crow = kbeg + 4 * half;
         const bool full = kbeg + 8 * nkb <= kend;
-        if (Q.gelu) {
-            if (full) dw_loop<true, false>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs);
-            else dw_loop<true, true>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs);
-        } else {
-            if (full) dw_loop<false, false>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs);
-            else dw_loop<false, true>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs);
+#define DW_RUN(BFV) \
+        if (Q.gelu) { \
+            if (full) dw_loop<true, false, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
+            else dw_loop<true, true, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
+        } else { \
+            if (full) dw_loop<false, false, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
+            else dw_loop<false, true, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
         }
+        if (Q.bf16) { DW_RUN(true) } else { DW_RUN(false) }
+#undef DW_RUN
     }
     // bias gradient: column sums of the gradient operand; the two lane halves hold different token rows
     bs.x = xor32_sum(bs.x); bs.y = xor32_sum(bs.y);

@@ -36,6 +36,7 @@ struct FusedFwdP {
     // xhat0, rstd0, ids32 to global for the backward
     const float *e_E, *e_pos, *e_g, *e_b; const int64_t* e_ids; GatherP e_gp; DropP e_drop; int e_V;
     float *e_X0, *e_xhat, *e_rstd; int* e_ids32;
+    int xout_f32;           // bf16 storage: Xout is the LAST layer's output, which stays an fp32 tensor (logits / API)
 };
 
 
@@ -75,6 +76,49 @@ __device__ __forceinline__ void gst(float* p, float v) { *(AS_GLOBAL float*)p = 
 __device__ __forceinline__ int gldi(const int* p) { return *(const AS_GLOBAL int*)p; }
 
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// ---------------------------------------------------------------------------------------------
+// bf16 storage (cfg.storage = 1, config C2).  BF = true instantiations keep every tensor that crosses a kernel boundary
+// inside the block stack -- the activations saved for the backward, the inter-block gradients, the operands of the
+// weight-gradient products -- as bf16 (behind the same float* the fp32 build uses: element e lives at byte 2e), read
+// the Linear weights from a bf16 shadow of the fp32 masters, and feed v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+// LDS tiles, LayerNorm, softmax, GELU, dropout and all statistics stay fp32.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32 (round to nearest even)
+    const bf16x2_t r = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+__device__ __forceinline__ u32x4 pk8(const f32x4& a, const f32x4& b) {
+    return u32x4{pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w)};
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// activation tensor accessors: 4 consecutive elements at element index e (16 B fp32 / 8 B bf16), or one element
+template <bool BF> __device__ __forceinline__ f32x4 ald4(const float* base, long e) {
+    if constexpr (BF) {
+        const u32x2 r = *reinterpret_cast<const AS_GLOBAL u32x2*>((const AS_GLOBAL char*)base + 2 * e);
+        return f32x4{bf_lo(r.x), bf_hi(r.x), bf_lo(r.y), bf_hi(r.y)};
+    } else return gld4(base + e);
+}
+template <bool BF> __device__ __forceinline__ void ast4(float* base, long e, const f32x4& v) {
+    if constexpr (BF) *reinterpret_cast<AS_GLOBAL u32x2*>((AS_GLOBAL char*)base + 2 * e) = u32x2{pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
+    else gst4(base + e, v);
+}
+template <bool BF> __device__ __forceinline__ float ald(const float* base, long e) {
+    if constexpr (BF) return bf_lo(*reinterpret_cast<const AS_GLOBAL unsigned short*>((const AS_GLOBAL char*)base + 2 * e));
+    else return gld(base + e);
+}
+template <bool BF> __device__ __forceinline__ void ast(float* base, long e, float v) {
+    if constexpr (BF) *reinterpret_cast<AS_GLOBAL unsigned short*>((AS_GLOBAL char*)base + 2 * e) = (unsigned short)(pk_bf16(v, 0.f) & 0xFFFFu);
+    else gst(base + e, v);
+}
 
 
 
@@ -148,38 +192,92 @@ __device__ __forceinline__ f32x4 lowpass_tab(const float* __restrict__ spec, int
     return low * (1.0f / (float)L);
 }
 
-// weight fragments: issue the loads of a whole 64-deep K chunk, use them later (latency hidden by the caller)
-__device__ __forceinline__ void load_w8(const float* __restrict__ gw, f32x4 (&w)[8]) {
+// Weight fragments of a K-deep chunk (K = 64 or 32) in MFMA B-operand registers: issue the loads of the whole chunk,
+// use them later (latency hidden by the caller).  The k values a lane holds follow its A fragment:
+//   fp32 (v_mfma_f32_32x32x2_f32): per 8-deep k-block kb, lane half h holds k = 8 kb + 4 h + {0..3}  (one 16-byte load)
+//   bf16 (v_mfma_f32_32x32x16_bf16): per 16-deep k-block s, lane half h holds k = 16 s + 8 h + {0..7}   (one 16-byte load)
+// so the per-lane element offsets carry KH = 4 h (fp32) resp. 8 h (bf16), for the LDS rows and the weight rows alike.
+template <bool BF, int K> struct WFrag;
+template <int K> struct WFrag<false, K> { f32x4 w[K / 8]; };
+template <int K> struct WFrag<true, K> { u32x4 w[K / 16]; };
+
+// "rows x weights": B[k][n] = W[n][k], lane n reads its own weight row (contiguous in k); e = element offset of
+// W[n][k0 + KH] in the fp32 master (BF = false) resp. the bf16 shadow (BF = true) behind `base`
+template <bool BF, int K>
+__device__ __forceinline__ void load_w(const float* __restrict__ base, long e, WFrag<BF, K>& f) {
+    if constexpr (BF) {
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) w[kb] = gld4(gw + 8 * kb);
-}
-__device__ __forceinline__ void mma_w8(const float* __restrict__ sa, const f32x4 (&w)[8], f32x16& acc) {
+        for (int s = 0; s < K / 16; ++s) f.w[s] = *reinterpret_cast<const AS_GLOBAL u32x4*>((const AS_GLOBAL char*)base + 2 * (e + 16 * s));
+    } else {
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        const f32x4 a = ld4(sa + 8 * kb);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
+        for (int kb = 0; kb < K / 8; ++kb) f.w[kb] = gld4(base + e + 8 * kb);
     }
 }
-template <int LDW>
-__device__ __forceinline__ void load_wT8(const float* __restrict__ gw, f32x4 (&w)[8]) {
+// "x . W": B[k][j] = W[k][j], lane j reads a weight column (stride LDW elements): coalesced dword (fp32) or
+// halfword (bf16) loads; e = element offset of W[k0 + KH][j]
+template <bool BF, int K, int LDW>
+__device__ __forceinline__ void load_wT(const float* __restrict__ base, long e, WFrag<BF, K>& f) {
+    if constexpr (BF) {
+        const AS_GLOBAL unsigned short* g = reinterpret_cast<const AS_GLOBAL unsigned short*>((const AS_GLOBAL char*)base + 2 * e);
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        w[kb].x = gld(gw + (8 * kb + 0) * LDW); w[kb].y = gld(gw + (8 * kb + 1) * LDW);
-        w[kb].z = gld(gw + (8 * kb + 2) * LDW); w[kb].w = gld(gw + (8 * kb + 3) * LDW);
+        for (int s = 0; s < K / 16; ++s) {
+            unsigned h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = g[(16 * s + j) * LDW];
+            f.w[s] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        }
+    } else {
+        const float* gw = base + e;
+#pragma unroll
+        for (int kb = 0; kb < K / 8; ++kb) {
+            f.w[kb].x = gld(gw + (8 * kb + 0) * LDW); f.w[kb].y = gld(gw + (8 * kb + 1) * LDW);
+            f.w[kb].z = gld(gw + (8 * kb + 2) * LDW); f.w[kb].w = gld(gw + (8 * kb + 3) * LDW);
+        }
+    }
+}
+// acc += rows(sa) . frag: sa = LDS row of this lane + k0 + KH (fp32 tile; converted to bf16 on the way for BF)
+template <bool BF, int K>
+__device__ __forceinline__ void mma_w(const float* __restrict__ sa, const WFrag<BF, K>& f, f32x16& acc) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int s = 0; s < K / 16; ++s) acc = mfma_bf16(pk8(ld4(sa + 16 * s), ld4(sa + 16 * s + 4)), f.w[s], acc);
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < K / 8; ++kb) {
+            const f32x4 a = ld4(sa + 8 * kb);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], f.w[kb][s], acc, 0, 0, 0);
+        }
+    }
+}
+// both operands from LDS rows (k contiguous in each; pointers carry KH): acc += rows(sa) . rows(sb)^T over K
+template <bool BF, int K>
+__device__ __forceinline__ void mma_ll(const float* __restrict__ sa, const float* __restrict__ sb, f32x16& acc) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int s = 0; s < K / 16; ++s)
+            acc = mfma_bf16(pk8(ld4(sa + 16 * s), ld4(sa + 16 * s + 4)), pk8(ld4(sb + 16 * s), ld4(sb + 16 * s + 4)), acc);
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < K / 8; ++kb) {
+            const f32x4 a = ld4(sa + 8 * kb), b = ld4(sb + 8 * kb);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+        }
     }
 }
 
 // LayerNorm row pass over a 64 x 64 LDS tile held as two split-K partial tiles (16 lanes x float4 per row,
 // blockDim/16 rows per pass):  v = (tileA + tileB + bias) * dropout + residual ; xhat, rstd -> global ;
 // y = gamma*xhat + beta ; MIX: y = alpha*dsp + (1-alpha)*y.  Result -> LDS (outL, may be null) and global (outG).
-template <bool MIX>
+template <bool MIX, bool BF>
 __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, const float* __restrict__ tileB,
                                            const float* __restrict__ bias, const float* __restrict__ resid,
                                            const DropP& drop, const DropSeed& dseed, const float* __restrict__ gamma,
                                            const float* __restrict__ beta, float eps, const float* __restrict__ dsp,
                                            float alpha, float oma, long tok0, int L, float* __restrict__ outL,
-                                           float* __restrict__ outG, float* __restrict__ xhatG, float* __restrict__ rstdG) {
+                                           float* __restrict__ outG, float* __restrict__ xhatG, float* __restrict__ rstdG,
+                                           bool out_f32 = false /* BF: outG is an fp32 tensor (the last layer's output) */) {
     const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
     const int rpp = blockDim.x >> 4;
     const f32x4 bi = gld4(bias + lc), g = gld4(gamma + lc), be = gld4(beta + lc);
@@ -199,27 +297,14 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, cons
             const f32x4 xh = dl * rs;
             y = g * xh + be;
             if (MIX) y = alpha * ld4(dsp + r * FS + lc) + oma * y;
-            gst4(xhatG + e, xh);
-            gst4(outG + e, y);
+            ast4<BF>(xhatG, e, xh);
+            if (BF && out_f32) gst4(outG + e, y); else ast4<BF>(outG, e, y);
             if (lc == 0) gst(rstdG + tok0 + r, rs);
         }
         if (outL) st4(outL + r * FS + lc, y);
     }
 }
 
-// 4-deep (K = 32) versions of the weight fragment helpers, for products whose K is split across wave groups
-__device__ __forceinline__ void load_w4(const float* __restrict__ gw, f32x4 (&w)[4]) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) w[kb] = gld4(gw + 8 * kb);
-}
-__device__ __forceinline__ void mma_w4(const float* __restrict__ sa, const f32x4 (&w)[4], f32x16& acc) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        const f32x4 a = ld4(sa + 8 * kb);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[kb][s], acc, 0, 0, 0);
-    }
-}
 
 // Forward: 8 waves = 2 groups of 4 (each group tiles 64 tokens x 64 features as 2 x 2 waves), two waves per SIMD
 // so that one wave's MFMA chain overlaps the other's VALU / memory waits:
@@ -228,7 +313,7 @@ __device__ __forceinline__ void mma_w4(const float* __restrict__ sa, const f32x4
 //     row max / sum are exchanged through LDS, the two partial contexts are summed in a row pass;
 //   * dense and dense_2 split K across the groups (two partial tiles, summed by the LayerNorm row pass),
 //     dense_1 splits its four 64-wide output blocks.
-template <int DH>
+template <int DH, bool BF>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 #define PTYPE FusedFwdP
@@ -260,8 +345,10 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;              // this lane's output feature inside a 64-wide block
-    const long wrow = (long)col * 64 + 4 * half;
-    const int arow = (wm * 32 + l31) * FS + 4 * half;
+    constexpr int KHM = BF ? 8 : 4;             // k values per lane half and k-block (see WFrag)
+    const int KH = KHM * half;
+    const long wrow = (long)col * 64 + KH;
+    const int arow = (wm * 32 + l31) * FS + KH;
     float* const trash = KARG(FusedFwdP, trash) + 4 * lane;
 
     STAMP(0);
@@ -272,10 +359,10 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     const auto R1_wq = KARG(FusedFwdP, wq);
     // every global LOAD of a phase is issued before the phase's first global STORE: vmcnt retires in issue
     // order, so a load queued behind stores would wait for their write acknowledgements
-    f32x4 wA[8], wB[8];
+    WFrag<BF, 64> wA, wB;
     float qkv_bias[3] = {0.f, 0.f, 0.f};
     if (grp == 1) {
-        load_w8(R1_wq + wrow, wA);
+        load_w<BF, 64>(R1_wq, wrow, wA);
         qkv_bias[0] = gld(KARG(FusedFwdP, bq) + col); qkv_bias[1] = gld(KARG(FusedFwdP, bk) + col);
         qkv_bias[2] = gld(KARG(FusedFwdP, bv) + col);
     }
@@ -322,8 +409,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
             if (ok) {
                 const f32x4 xh = dl * rs;
                 y = (eg * xh + eb) * drop_mult4(KARG(FusedFwdP, e_drop), dseed, (uint64_t)e >> 2);
-                gst4(KARG(FusedFwdP, e_xhat) + e, xh);
-                gst4(KARG(FusedFwdP, e_X0) + e, y);
+                ast4<BF>(KARG(FusedFwdP, e_xhat), e, xh);
+                ast4<BF>(KARG(FusedFwdP, e_X0), e, y);
                 if (c4 == 0) gst(KARG(FusedFwdP, e_rstd) + tok0 + r, rs);
             }
             st4(sX + r * FS + c4, y);
@@ -332,7 +419,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int idx = tid + p * 512, r = idx >> 4, c4 = (idx & 15) << 2;
-        f32x4 v = gld4(R1_X + (tok0 + min(r, L - 1)) * 64 + c4);
+        f32x4 v = ald4<BF>(R1_X, (tok0 + min(r, L - 1)) * 64 + c4);
         if (r >= L) v = f32x4{0, 0, 0, 0};
         st4(sX + r * FS + c4, v);
     }
@@ -368,9 +455,9 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            if (which == 0) { load_w8(R2_wk + wrow, wB); mma_w8(sX + arow, wA, acc); }
-            else if (which == 1) { load_w8(R2_wv + wrow, wA); mma_w8(sX + arow, wB, acc); }
-            else mma_w8(sX + arow, wA, acc);
+            if (which == 0) { load_w<BF, 64>(R2_wk, wrow, wB); mma_w<BF, 64>(sX + arow, wA, acc); }
+            else if (which == 1) { load_w<BF, 64>(R2_wv, wrow, wA); mma_w<BF, 64>(sX + arow, wB, acc); }
+            else mma_w<BF, 64>(sX + arow, wA, acc);
             const float bias = qkv_bias[which];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -449,7 +536,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
                 if (ok) {
                     const f32x4 xh = dl * rs;
                     y = g * xh + be;
-                    gst4(R2_xhat_f + e, xh);
+                    ast4<BF>(R2_xhat_f, e, xh);
                     if (R2_dsp) gst4(R2_dsp + e, y);
                     if (lc == 0) gst(R2_rstd_f + (tok0 + t), rs);
                 }
@@ -458,8 +545,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
         }
     }
     // dense weights for phase 4 (this group's K half), held across the attention
-    f32x4 wO[4];
-    load_w4(R2_wo + wrow + 32 * grp, wO);
+    WFrag<BF, 32> wO;
+    load_w<BF, 32>(R2_wo, wrow + 32 * grp, wO);
     lds_barrier();
     // q, k, v -> global as whole rows, 16 B per lane (per-lane dword stores are store-issue bound)
     {
@@ -469,9 +556,9 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
             const int r = r0 + lr;
             if (r < L) {
                 const long e = (tok0 + r) * 64 + lc;
-                gst4(R2_q + e, ld4(sQ + r * FS + lc));
-                gst4(R2_k + e, ld4(sK + r * FS + lc));
-                gst4(R2_v + e, f32x4{sVt[lc * FS + r], sVt[(lc + 1) * FS + r], sVt[(lc + 2) * FS + r], sVt[(lc + 3) * FS + r]});
+                ast4<BF>(R2_q, e, ld4(sQ + r * FS + lc));
+                ast4<BF>(R2_k, e, ld4(sK + r * FS + lc));
+                ast4<BF>(R2_v, e, f32x4{sVt[lc * FS + r], sVt[(lc + 1) * FS + r], sVt[(lc + 2) * FS + r], sVt[(lc + 3) * FS + r]});
             }
         }
     }
@@ -497,14 +584,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             float mx = -INFINITY;
             if (act) {
-                const float* ka = sK + (32 * kt + l31) * FS + head * DH + 4 * half;
-                const float* qb = sQ + query * FS + head * DH + 4 * half;
-#pragma unroll
-                for (int kb = 0; kb < DH / 8; ++kb) {
-                    const f32x4 a = ld4(ka + 8 * kb), q4 = ld4(qb + 8 * kb);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], q4[s], st, 0, 0, 0);
-                }
+                mma_ll<BF, DH>(sK + (32 * kt + l31) * FS + head * DH + KH, sQ + query * FS + head * DH + KH, st);
                 // scale, mask (-10000, additive, fp32)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -544,7 +624,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
                     f32x4 m = {1.f, 1.f, 1.f, 1.f};
                     if (query < L && key0 < Lp) {
                         const long e = (((long)b * heads + head) * L + query) * Lp + key0;
-                        gst4(R3_probs + e, p);
+                        ast4<BF>(R3_probs, e, p);
                         m = drop_mult4(R3_drop_p, dseed, (uint64_t)e >> 2);
                     }
                     p = p * m;
@@ -559,6 +639,18 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
                     for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
                     const bool crow_ok = 32 * ct + l31 < DH;
                     const float* va = sVt + (head * DH + 32 * ct + (crow_ok ? l31 : 0)) * FS + 32 * kt + 4 * half;
+                    if constexpr (BF) {
+                        // the P^T accumulator tile is the B operand as it stands: registers 8s .. 8s+7 of a lane half are
+                        // keys 16 s + 8 (j >> 2) + 4 h + (j & 3), so the V^T fragment takes the same two groups of 4 keys
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            f32x4 a0 = ld4(va + 16 * s2), a1 = ld4(va + 16 * s2 + 8);
+                            if (!crow_ok) { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }
+                            const u32x4 pb = {pk_bf16(st[8 * s2], st[8 * s2 + 1]), pk_bf16(st[8 * s2 + 2], st[8 * s2 + 3]),
+                                              pk_bf16(st[8 * s2 + 4], st[8 * s2 + 5]), pk_bf16(st[8 * s2 + 6], st[8 * s2 + 7])};
+                            cacc = mfma_bf16(pk8(a0, a1), pb, cacc);
+                        }
+                    } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 a = ld4(va + 8 * g);
@@ -566,6 +658,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], st[4 * g + j], cacc, 0, 0, 0);
+                    }
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -586,7 +679,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
                 f32x4 v = {0, 0, 0, 0};
                 if (r < 32 * nt) { v = ld4(sC + r * FS + lc); if (nt == 2) v += ld4(sE + r * FS + lc); }
                 st4(sC + r * FS + lc, v);
-                if (r < L) gst4(R3_ctx + (tok0 + r) * 64 + lc, v);
+                if (r < L) ast4<BF>(R3_ctx, (tok0 + r) * 64 + lc, v);
             }
         }
     }
@@ -607,18 +700,18 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     float ffn_bias[2];
     // ---- phase 4: dense (K split across the groups) + dropout + residual + LayerNorm + alpha mix
     {
-        load_w8(R4_w1 + (long)(128 * grp + col) * 64 + 4 * half, wA);      // first dense_1 block of this group
+        load_w<BF, 64>(R4_w1, (long)(128 * grp + col) * 64 + KH, wA);      // first dense_1 block of this group
         ffn_bias[0] = gld(KARG(FusedFwdP, b1) + 128 * grp + col); ffn_bias[1] = gld(KARG(FusedFwdP, b1) + 128 * grp + 64 + col);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w4(sC + arow + 32 * grp, wO, acc);
+        mma_w<BF, 32>(sC + arow + 32 * grp, wO, acc);
         float* part = grp == 0 ? sQ : sK;                                  // sQ / sK are dead: partial tiles
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
     }
     lds_barrier();
-    ln_rows_64<true>(sQ, sK, R4_bo, sX, R4_drop_o, dseed, R4_a_g, R4_a_b, R4_eps, sD, R4_alpha, R4_oma, tok0, L, sH, R4_hmix, R4_xhat_a,
+    ln_rows_64<true, BF>(sQ, sK, R4_bo, sX, R4_drop_o, dseed, R4_a_g, R4_a_b, R4_eps, sD, R4_alpha, R4_oma, tok0, L, sH, R4_hmix, R4_xhat_a,
                      R4_rstd_a);
     lds_barrier();
 
@@ -633,14 +726,14 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c256 = (2 * grp + i) * 64 + col;
-            f32x4 (&wcur)[8] = i ? wB : wA;
-            f32x4 (&wnxt)[8] = i ? wA : wB;
-            if (i == 0) load_w8(R5_w1 + (long)(c256 + 64) * 64 + 4 * half, wnxt);
-            else load_w8(R5_w2 + (long)col * 256 + 128 * grp + 4 * half, wnxt);     // first dense_2 chunk of this group
+            WFrag<BF, 64>& wcur = i ? wB : wA;
+            WFrag<BF, 64>& wnxt = i ? wA : wB;
+            if (i == 0) load_w<BF, 64>(R5_w1, (long)(c256 + 64) * 64 + KH, wnxt);
+            else load_w<BF, 64>(R5_w2, (long)col * 256 + 128 * grp + KH, wnxt);     // first dense_2 chunk of this group
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mma_w8(sa, wcur, acc);
+            mma_w<BF, 64>(sa, wcur, acc);
             const float bias = ffn_bias[i];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -661,7 +754,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
         for (int idx = tid; idx < 64 * 64; idx += 512) {
             const int r = idx >> 6, c4 = (idx & 63) << 2;
             f32x4 v = ld4(sU + r * FU + c4);
-            if (r < L) gst4(R6_u + (tok0 + r) * 256 + c4, v);
+            if (r < L) ast4<BF>(R6_u, (tok0 + r) * 256 + c4, v);
             v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
             st4(sU + r * FU + c4, v);
         }
@@ -669,10 +762,10 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* sa = sU + (wm * 32 + l31) * FU + 128 * grp + 4 * half;
-        load_w8(R6_w2 + (long)col * 256 + 128 * grp + 64 + 4 * half, wB);
-        mma_w8(sa, wA, acc);                                 // chunk 0 of this group sits in wA
-        mma_w8(sa + 64, wB, acc);
+        const float* sa = sU + (wm * 32 + l31) * FU + 128 * grp + KH;
+        load_w<BF, 64>(R6_w2, (long)col * 256 + 128 * grp + 64 + KH, wB);
+        mma_w<BF, 64>(sa, wA, acc);                          // chunk 0 of this group sits in wA
+        mma_w<BF, 64>(sa + 64, wB, acc);
         float* part = grp == 0 ? sX : sE;                    // sX / sE are dead: partial tiles
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
@@ -687,8 +780,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     const auto R7_ff_g = KARG(FusedFwdP, ff_g);
     const auto R7_rstd_ff = KARG(FusedFwdP, rstd_ff);
     const auto R7_xhat_ff = KARG(FusedFwdP, xhat_ff);
-    ln_rows_64<false>(sX, sE, R7_b2, sH, R7_drop_ff, dseed, R7_ff_g, R7_ff_b, R7_eps, nullptr, 0.f, 1.f, tok0, L, nullptr, R7_Xout,
-                      R7_xhat_ff, R7_rstd_ff);
+    ln_rows_64<false, BF>(sX, sE, R7_b2, sH, R7_drop_ff, dseed, R7_ff_g, R7_ff_b, R7_eps, nullptr, 0.f, 1.f, tok0, L, nullptr, R7_Xout,
+                          R7_xhat_ff, R7_rstd_ff, KARG(FusedFwdP, xout_f32) != 0);
     STAMP(8);
 }
 #undef PTYPE
@@ -743,20 +836,12 @@ __device__ __forceinline__ void seq_partial_64(const f32x4& v, float* __restrict
     }
 }
 
-template <int LDW>
-__device__ __forceinline__ void load_wT4(const float* __restrict__ gw, f32x4 (&w)[4]) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        w[kb].x = gld(gw + (8 * kb + 0) * LDW); w[kb].y = gld(gw + (8 * kb + 1) * LDW);
-        w[kb].z = gld(gw + (8 * kb + 2) * LDW); w[kb].w = gld(gw + (8 * kb + 3) * LDW);
-    }
-}
 
 // Backward: 8 waves = 2 groups of 4, two waves per SIMD.  dU splits its four 64-wide blocks across the groups;
 // dH, dC and the QKV input-gradient split K (two partial tiles, summed by the next row pass); attention backward
 // runs (query tile, key tile) per wave and the 6 dQ/dK/dV tiles of a head on 6 of the 8 waves; the two DFT
 // sources of the FrequencyLayer backward run one per group.
-template <int DH>
+template <int DH, bool BF>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #define PTYPE FusedBwdP
@@ -786,7 +871,9 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;
-    const int arow = (wm * 32 + l31) * FS + 4 * half;
+    constexpr int KHM = BF ? 8 : 4;
+    const int KH = KHM * half;
+    const int arow = (wm * 32 + l31) * FS + KH;
     float* const trash = KARG(FusedBwdP, trash) + 4 * lane;
 
     STAMP(0);
@@ -804,8 +891,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R1_tw = KARG(FusedBwdP, tw);
     const auto R1_w2 = KARG(FusedBwdP, w2);
     const auto R1_xhat_ff = KARG(FusedBwdP, xhat_ff);
-    f32x4 wA[8], wB[8];
-    load_wT8<256>(R1_w2 + (long)(4 * half) * 256 + 128 * grp + col, wA);          // first dU block of this group
+    WFrag<BF, 64> wA, wB;
+    load_wT<BF, 64, 256>(R1_w2, (long)KH * 256 + 128 * grp + col, wA);             // first dU block of this group
     build_twiddle_table(R1_tw, L, cb, sTab);
     // stage A1's operands are requested BEFORE the u tile: loads return in issue order, so the LayerNorm row pass waits
     // only for them while the 64 KB of u are still in flight
@@ -821,12 +908,12 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             if (r < L) {
                 if (r == L - 1)
                     for (int sp = 0; sp < R1_dh_nsplit; ++sp) dy[i] += gld4(R1_dh_slabs + sp * R1_dh_stride + (long)b * 64 + lc);
-                xh[i] = gld4(R1_xhat_ff + e); rs[i] = gld(R1_rstd_ff + tok0 + r);
+                xh[i] = ald4<BF>(R1_xhat_ff, e); rs[i] = gld(R1_rstd_ff + tok0 + r);
             }
         } else {                                        // branch-free (rows past L re-read row L-1, then zeroed)
             const bool ok = r < L;
             const long ec = (tok0 + min(r, L - 1)) * 64 + lc;
-            const f32x4 d4 = gld4(R1_dY + ec), x4 = gld4(R1_xhat_ff + ec);
+            const f32x4 d4 = ald4<BF>(R1_dY, ec), x4 = ald4<BF>(R1_xhat_ff, ec);
             const float r1 = gld(R1_rstd_ff + tok0 + min(r, L - 1));
             dy[i] = ok ? d4 : f32x4{0, 0, 0, 0}; xh[i] = ok ? x4 : f32x4{0, 0, 0, 0}; rs[i] = ok ? r1 : 0.f;
         }
@@ -839,7 +926,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * 512, r = idx >> 6, c4 = (idx & 63) << 2;
-            uv[i] = gld4(gu + (tok0 + min(r, L - 1)) * 256 + c4);
+            uv[i] = ald4<BF>(gu, (tok0 + min(r, L - 1)) * 256 + c4);
         }
         // (the tile goes to LDS after the LayerNorm row pass below: its 64 KB arrive while that pass computes)
     }
@@ -858,7 +945,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             const f32x4 dz = rs[i] * (gg - m1 - xh[i] * m2);
             sg += dy[i] * xh[i]; sb += dy[i];
             f32x4 dt = {0, 0, 0, 0};
-            if (ok) { dt = dz * drop_mult4(R1_drop_ff, dseed, (uint64_t)e >> 2); gst4(R1_dT + e, dt); }
+            if (ok) { dt = dz * drop_mult4(R1_drop_ff, dseed, (uint64_t)e >> 2); ast4<BF>(R1_dT, e, dt); }
             st4(sAcc + r * FS + lc, dz);
             st4(sT + r * FS + lc, dt);
         }
@@ -883,14 +970,14 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int blk = 2 * grp + i, c256 = blk * 64 + col;
-            f32x4 (&wcur)[8] = i ? wB : wA;
-            f32x4 (&wnxt)[8] = i ? wA : wB;
-            if (i == 0) load_wT8<256>(R2_w2 + (long)(4 * half) * 256 + c256 + 64, wnxt);
-            else load_wT8<64>(R2_w1 + (long)(128 * grp + 4 * half) * 64 + col, wnxt);      // first dH chunk of this group
+            WFrag<BF, 64>& wcur = i ? wB : wA;
+            WFrag<BF, 64>& wnxt = i ? wA : wB;
+            if (i == 0) load_wT<BF, 64, 256>(R2_w2, (long)KH * 256 + c256 + 64, wnxt);
+            else load_wT<BF, 64, 64>(R2_w1, (long)(128 * grp + KH) * 64 + col, wnxt);      // first dH chunk of this group
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mma_w8(sa, wcur, acc);
+            mma_w<BF, 64>(sa, wcur, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
@@ -903,35 +990,35 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     // dU -> global as whole rows, 16 B per lane (operand of the dense_1 weight gradient)
     for (int idx = tid; idx < 64 * 64; idx += 512) {
         const int r = idx >> 6, c4 = (idx & 63) << 2;
-        if (r < L) gst4(R2_dU + (tok0 + r) * 256 + c4, ld4(sdU + r * FU + c4));
+        if (r < L) ast4<BF>(R2_dU, (tok0 + r) * 256 + c4, ld4(sdU + r * FU + c4));
     }
 
     STAMP(2);
     const auto R3_w1 = KARG(FusedBwdP, w1);
     const auto R3_wo = KARG(FusedBwdP, wo);
     // ---- stage A3: dH = dU . W1, K split: group g owns inner units [128g, 128g+128) -> partial tiles sG / sdF
-    f32x4 wO[4];
+    WFrag<BF, 32> wO;
     f32x4 pq[2], pk[2], pv[2], xa[2], xf[2];                 // stage B1's operands, prefetched below
     float ra[2], rf[2];
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* sa = sdU + (wm * 32 + l31) * FU + 128 * grp + 4 * half;
-        load_wT8<64>(R3_w1 + (long)(128 * grp + 64 + 4 * half) * 64 + col, wB);
-        load_wT4<64>(R3_wo + (long)(32 * grp + 4 * half) * 64 + col, wO);          // dense^T half for stage B2
+        const float* sa = sdU + (wm * 32 + l31) * FU + 128 * grp + KH;
+        load_wT<BF, 64, 64>(R3_w1, (long)(128 * grp + 64 + KH) * 64 + col, wB);
+        load_wT<BF, 32, 64>(R3_wo, (long)(32 * grp + KH) * 64 + col, wO);          // dense^T half for stage B2
         // stage B1's operands (q, k, v, xhat of both LayerNorms: 80 KB per sequence) are requested here, AFTER the weight
         // fragments this stage waits for (loads return in issue order), and land while the MFMAs below run
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * i + lr;
             const long ec = (tok0 + min(r, L - 1)) * 64 + lc;
-            pq[i] = gld4(KARG(FusedBwdP, q) + ec); pk[i] = gld4(KARG(FusedBwdP, k) + ec); pv[i] = gld4(KARG(FusedBwdP, v) + ec);
-            xa[i] = gld4(KARG(FusedBwdP, xhat_a) + ec); xf[i] = gld4(KARG(FusedBwdP, xhat_f) + ec);
+            pq[i] = ald4<BF>(KARG(FusedBwdP, q), ec); pk[i] = ald4<BF>(KARG(FusedBwdP, k), ec); pv[i] = ald4<BF>(KARG(FusedBwdP, v), ec);
+            xa[i] = ald4<BF>(KARG(FusedBwdP, xhat_a), ec); xf[i] = ald4<BF>(KARG(FusedBwdP, xhat_f), ec);
             ra[i] = gld(KARG(FusedBwdP, rstd_a) + tok0 + min(r, L - 1)); rf[i] = gld(KARG(FusedBwdP, rstd_f) + tok0 + min(r, L - 1));
         }
-        mma_w8(sa, wA, acc);                                 // chunk 0 of this group sits in wA
-        mma_w8(sa + 64, wB, acc);
+        mma_w<BF, 64>(sa, wA, acc);                          // chunk 0 of this group sits in wA
+        mma_w<BF, 64>(sa + 64, wB, acc);
         float* part = grp == 0 ? sG : sdF;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
@@ -989,7 +1076,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             if (ok) {
                 dO = dza * drop_mult4(R4_drop_o, dseed, (uint64_t)e >> 2);
                 dF = dzf * drop_mult4(R4_drop_f, dseed, (uint64_t)e >> 2);
-                gst4(R4_dO + e, dO);
+                ast4<BF>(R4_dO, e, dO);
             }
             st4(sAcc + r * FS + lc, dza + dzf);
             st4(sT + r * FS + lc, dO);
@@ -1008,7 +1095,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w4(sT + arow + 32 * grp, wO, acc);
+        mma_w<BF, 32>(sT + arow + 32 * grp, wO, acc);
         float* part = grp == 0 ? sG : sPm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
@@ -1049,22 +1136,14 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                     pp[g] = f32x4{0, 0, 0, 0}; mm[g] = pp[g];
                     if (query < L && key0 < Lp) {
                         const long e = (((long)b * heads + head) * L + query) * Lp + key0;
-                        pp[g] = gld4(R6_probs + e);
+                        pp[g] = ald4<BF>(R6_probs, e);
                         mm[g] = drop_mult4(R6_drop_p, dseed, (uint64_t)e >> 2);
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) da[r] = 0.f;
-                if (kt < nt && qt < nt) {
-                    const float* va = sV + (32 * kt + l31) * FS + hc + 4 * half;
-                    const float* cb_ = sG + query * FS + hc + 4 * half;
-#pragma unroll
-                    for (int kb = 0; kb < DH / 8; ++kb) {
-                        const f32x4 a = ld4(va + 8 * kb), c4 = ld4(cb_ + 8 * kb);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) da = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], c4[s], da, 0, 0, 0);
-                    }
-                }
+                if (kt < nt && qt < nt)
+                    mma_ll<BF, DH>(sV + (32 * kt + l31) * FS + hc + KH, sG + query * FS + hc + KH, da);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1103,6 +1182,24 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                     if (rt < nt) {
                         const float* bsrc = kind == 0 ? sK : kind == 1 ? sQ : sG;
                         const float* asrc = kind == 2 ? sPm : sS;
+                        if constexpr (BF) {
+#pragma unroll 2
+                            for (int s2 = 0; s2 < 2 * nt; ++s2) {          // K = 32*nt tokens, 16 per bf16 MFMA: k = 16 s2 + 8 h + j
+                                f32x4 a0, a1;
+                                if (kind == 0) {                           // dQ = dS . K : A k-major from sS
+                                    const float* ap = asrc + (16 * s2 + KH) * FS + 32 * rt + l31;
+                                    a0 = f32x4{ap[0], ap[FS], ap[2 * FS], ap[3 * FS]};
+                                    a1 = f32x4{ap[4 * FS], ap[5 * FS], ap[6 * FS], ap[7 * FS]};
+                                } else {                                   // dK = dS^T . Q ; dV = Drop(P)^T . dC
+                                    const float* ap = asrc + (32 * rt + l31) * FS + 16 * s2 + KH;
+                                    a0 = ld4(ap); a1 = ld4(ap + 4);
+                                }
+                                const float* bp = bsrc + (16 * s2 + KH) * FS + cc;
+                                f32x4 b0 = {bp[0], bp[FS], bp[2 * FS], bp[3 * FS]}, b1 = {bp[4 * FS], bp[5 * FS], bp[6 * FS], bp[7 * FS]};
+                                if (!cok) { b0 = f32x4{0, 0, 0, 0}; b1 = b0; }
+                                acc = mfma_bf16(pk8(a0, a1), pk8(b0, b1), acc);
+                            }
+                        } else {
 #pragma unroll 4
                         for (int kb = 0; kb < 4 * nt; ++kb) {              // K = 32*nt tokens
                             f32x4 a;
@@ -1119,6 +1216,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w1, acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w2, acc, 0, 0, 0);
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w3, acc, 0, 0, 0);
+                        }
                         }
                     }
                 }
@@ -1150,9 +1248,9 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             const int r = 32 * i + lr;
             if (r < L) {
                 const long e = (tok0 + r) * 64 + lc;
-                gst4(R6_dq + e, ld4(sQ + r * FS + lc));
-                gst4(R6_dk + e, ld4(sK + r * FS + lc));
-                gst4(R6_dv + e, ld4(sV + r * FS + lc));
+                ast4<BF>(R6_dq, e, ld4(sQ + r * FS + lc));
+                ast4<BF>(R6_dk, e, ld4(sK + r * FS + lc));
+                ast4<BF>(R6_dv, e, ld4(sV + r * FS + lc));
             }
         }
     }
@@ -1166,12 +1264,12 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const long wofs = (long)(4 * half) * 64 + col;
-        f32x4 wk4[4];
-        if (grp == 0) { load_wT8<64>(R7_wq + wofs, wA); load_wT4<64>(R7_wk + wofs, wk4); }
-        else { load_wT4<64>(R7_wk + wofs + 32 * 64, wk4); load_wT8<64>(R7_wv + wofs, wA); }
-        mma_w8((grp == 0 ? sQ : sV) + arow, wA, acc);
-        mma_w4(sK + arow + 32 * grp, wk4, acc);
+        const long wofs = (long)KH * 64 + col;
+        WFrag<BF, 32> wk4;
+        if (grp == 0) { load_wT<BF, 64, 64>(R7_wq, wofs, wA); load_wT<BF, 32, 64>(R7_wk, wofs, wk4); }
+        else { load_wT<BF, 32, 64>(R7_wk, wofs + 32 * 64, wk4); load_wT<BF, 64, 64>(R7_wv, wofs, wA); }
+        mma_w<BF, 64>((grp == 0 ? sQ : sV) + arow, wA, acc);
+        mma_w<BF, 32>(sK + arow + 32 * grp, wk4, acc);
         float* part = grp == 0 ? sG : sPm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
@@ -1193,7 +1291,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * i + lr;
-            f32x4 x = gld4(R8_X + (tok0 + min(r, L - 1)) * 64 + lc);
+            f32x4 x = ald4<BF>(R8_X, (tok0 + min(r, L - 1)) * 64 + lc);
             if (r >= L) x = f32x4{0, 0, 0, 0};
             st4(sG + r * FS + lc, ld4(sG + r * FS + lc) + ld4(sPm + r * FS + lc) + ld4(sAcc + r * FS + lc));
             st4(sXin + r * FS + lc, x);
@@ -1261,8 +1359,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                 const f32x4 lowg = lowpass_tab(spec + cb * 128, t, lc, L, cb, sTab);
                 dx = ld4(sG + t * FS + lc) + b2 * df + lowg;
                 sb += df * (xv - lowx);
-                if (e_dz) { xh = gld4(e_xhat + e); rs = gld(e_rstd + tok0 + t); dx = dx * drop_mult4(e_drop, dseed, (uint64_t)e >> 2); }
-                else gst4(R8_dX + e, dx);
+                if (e_dz) { xh = ald4<BF>(e_xhat, e); rs = gld(e_rstd + tok0 + t); dx = dx * drop_mult4(e_drop, dseed, (uint64_t)e >> 2); }
+                else ast4<BF>(R8_dX, e, dx);
             }
             if (e_dz) {                                     // embedding LayerNorm backward on the finished row
                 const f32x4 gg = dx * g0;

@@ -23,6 +23,9 @@ struct TopFwdP {
     float alpha, oma, eps;
     DropP drop_f, drop_p, drop_o, drop_ff;
     long long* stamps;             // diagnostic: per-step shader clock of workgroup 0 (null in production)
+    // bf16 storage (BF instantiation): wk_sh / wv_sh = bf16 shadow of the key / value weights for the MFMA projections of
+    // all rows (as the full block kernel reads them); the one-row vector products keep the fp32 masters
+    const float *wk_sh, *wv_sh;
 };
 
 // keep-mask x scale of ONE element (common.h: DropSeed, drop_mult4)
@@ -83,7 +86,7 @@ __device__ __forceinline__ void ln_row(float v, float eps, float& xhat, float& r
     xhat = dl * rstd;
 }
 
-template <int DH>
+template <int DH, bool BF>
 __global__ void __launch_bounds__(256)
 top_fwd_kernel(const TopFwdP P) {
 #define PTYPE TopFwdP
@@ -114,15 +117,16 @@ top_fwd_kernel(const TopFwdP P) {
                 c_ab = gld(P.a_b + lane), c_ffg = gld(P.ff_g + lane), c_ffb = gld(P.ff_b + lane);
     // ---- load: x tile, ids, twiddles; K / V weight fragments for this wave's two 32 x 32 tiles
     const int wm = wave >> 1, wn = wave & 1, col = wn * 32 + l31;
-    const long wrow = (long)col * 64 + 4 * half;
-    f32x4 wA[8], wB[8];
-    load_w8(P.wk + wrow, wA);
-    load_w8(P.wv + wrow, wB);
+    const int KH = (BF ? 8 : 4) * half;
+    const long wrow = (long)col * 64 + KH;
+    WFrag<BF, 64> wA, wB;
+    load_w<BF, 64>(BF ? P.wk_sh : P.wk, wrow, wA);
+    load_w<BF, 64>(BF ? P.wv_sh : P.wv, wrow, wB);
     const float bias_k = gld(P.bk + col), bias_v = gld(P.bv + col);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
-        f32x4 v = gld4(P.X + (tok0 + min(r, L - 1)) * 64 + c4);      // branch-free: rows past L re-read row L-1, zeroed
+        f32x4 v = ald4<BF>(P.X, (tok0 + min(r, L - 1)) * 64 + c4);      // branch-free: rows past L re-read row L-1, zeroed
         if (r >= L) v = f32x4{0, 0, 0, 0};
         st4(sX + r * FS + c4, v);
     }
@@ -139,16 +143,16 @@ top_fwd_kernel(const TopFwdP P) {
 
     // ---- K, V projections of all rows (MFMA), spectrum of x (VALU)
     {
-        const int arow = (wm * 32 + l31) * FS + 4 * half;
+        const int arow = (wm * 32 + l31) * FS + KH;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w8(sX + arow, wA, acc);
+        mma_w<BF, 64>(sX + arow, wA, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sK[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + bias_k;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w8(sX + arow, wB, acc);
+        mma_w<BF, 64>(sX + arow, wB, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sV[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + bias_v;
     }
@@ -158,11 +162,11 @@ top_fwd_kernel(const TopFwdP P) {
     // q_last = x_last . Wq^T + bq  (4 lanes per output), and the k, v rows -> global (the backward reads them)
     {
         const float qv = gemv_rows_dot<64, 4>(wq4, sX + tl * FS, osl) + bq_n;
-        if (osl == 0) { sQ[on] = qv; gst(P.q + el + on, qv); }
+        if (osl == 0) { sQ[on] = qv; ast<BF>(P.q, el + on, qv); }
         const int lr = tid >> 4, lc = (tid & 15) << 2;
         for (int r = lr; r < L; r += 16) {
-            gst4(P.k + (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
-            gst4(P.v + (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
+            ast4<BF>(P.k, (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
+            ast4<BF>(P.v, (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
         }
     }
     // FrequencyLayer output of the last row (wave 0, lane = column):  src/model/bsarec.py:90-104
@@ -177,7 +181,7 @@ top_fwd_kernel(const TopFwdP P) {
         const float v = f * drop_mult1(KARG(TopFwdP, drop_f), dseed, (uint64_t)(el + c)) + xv;
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
-        gst(P.xhat_f + el + c, xh);
+        ast<BF>(P.xhat_f, el + c, xh);
         if (c == 0) gst(P.rstd_f + tok0 + tl, rs);
         sDsp[c] = c_fg * xh + c_fb;
     }
@@ -207,7 +211,7 @@ top_fwd_kernel(const TopFwdP P) {
         const float e = key < L ? __expf(s - mx) : 0.f;
         const float p = e / group_sum<64>(e);
         const long pe = (((long)b * heads + head) * L + tl) * Lp;
-        if (key < Lp) gst(P.probs + pe + key, p);
+        if (key < Lp) ast<BF>(P.probs, pe + key, p);
         sPd[head * 64 + key] = key < L ? p * drop_mult1(KARG(TopFwdP, drop_p), dseed, (uint64_t)(pe + key)) : 0.f;
     }
     lds_barrier();
@@ -220,7 +224,7 @@ top_fwd_kernel(const TopFwdP P) {
         for (int j = 0; j < 64; ++j) a4[j & 3] += sPd[head * 64 + j] * sV[j * FS + c];
         acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         sCtx[c] = acc;
-        gst(P.ctx + el + c, acc);
+        ast<BF>(P.ctx, el + c, acc);
     }
     lds_barrier();
     STAMP(4);
@@ -237,12 +241,12 @@ top_fwd_kernel(const TopFwdP P) {
         const float v = sG[c] * drop_mult1(KARG(TopFwdP, drop_o), dseed, (uint64_t)(el + c)) + sX[tl * FS + c];
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
-        gst(P.xhat_a + el + c, xh);
+        ast<BF>(P.xhat_a, el + c, xh);
         if (c == 0) gst(P.rstd_a + tok0 + tl, rs);
         const float a = c_ag * xh + c_ab;
         const float hm = P.alpha * sDsp[c] + P.oma * a;
         sHm[c] = hm;
-        gst(P.hmix + el + c, hm);
+        ast<BF>(P.hmix, el + c, hm);
     }
     lds_barrier();
     STAMP(6);
@@ -250,7 +254,7 @@ top_fwd_kernel(const TopFwdP P) {
     // ---- feed-forward (one row): u = hmix W1^T + b1 (one output per thread), y = gelu(u) W2^T + b2
     {
         const float u = gemv_rows_dot<64, 1>(w1r, sHm, 0) + b1_n;
-        gst(P.u + (tok0 + tl) * 256 + tid, u);
+        ast<BF>(P.u, (tok0 + tl) * 256 + tid, u);
         sG[tid] = gelu_f(u);
     }
     lds_barrier();
@@ -266,9 +270,9 @@ top_fwd_kernel(const TopFwdP P) {
         const float v = sQ[c] * drop_mult1(KARG(TopFwdP, drop_ff), dseed, (uint64_t)(el + c)) + sHm[c];
         float xh, rs;
         ln_row(v, P.eps, xh, rs);
-        gst(P.xhat_ff + el + c, xh);
+        ast<BF>(P.xhat_ff, el + c, xh);
         if (c == 0) gst(P.rstd_ff + tok0 + tl, rs);
-        gst(P.Xout + el + c, c_ffg * xh + c_ffb);
+        gst(P.Xout + el + c, c_ffg * xh + c_ffb);                 // the last layer's output is an fp32 tensor in every mode
     }
     STAMP(15);
 }
@@ -304,7 +308,7 @@ __device__ __forceinline__ float ln_row_bwd(float dy, float gamma, float xhat, f
     return rstd * (g - m1 - xhat * m2);
 }
 
-template <int DH>
+template <int DH, bool BF>
 __global__ void __launch_bounds__(256)
 top_bwd_kernel(const TopBwdP P) {
 #define PTYPE TopBwdP
@@ -358,12 +362,12 @@ top_bwd_kernel(const TopBwdP P) {
         for (int sp = 32; sp < ns; ++sp) part[0] += gld(P.dh_slabs + (long)sp * P.dh_stride + (long)b * 64 + c);
         dy = (part[0] + part[1]) + (part[2] + part[3]);
     }
-    const float xh_ff = gld(P.xhat_ff + el + c), g_ff = gld(P.ff_g + c), rs_ff = gld(P.rstd_ff + tok0 + tl);
-    const float xa = gld(P.xhat_a + el + c), xf = gld(P.xhat_f + el + c), g_a = gld(P.a_g + c), g_f = gld(P.f_g + c);
+    const float xh_ff = ald<BF>(P.xhat_ff, el + c), g_ff = gld(P.ff_g + c), rs_ff = gld(P.rstd_ff + tok0 + tl);
+    const float xa = ald<BF>(P.xhat_a, el + c), xf = ald<BF>(P.xhat_f, el + c), g_a = gld(P.a_g + c), g_f = gld(P.f_g + c);
     const float rs_a = gld(P.rstd_a + tok0 + tl), rs_f = gld(P.rstd_f + tok0 + tl);
-    const float bt = gld(P.sqrt_beta + c), low_l = gld(P.low + el + c), x_l = gld(P.X + el + c);
-    const float u_mine = gld(P.u + (tok0 + tl) * 256 + tid);
-    if (tid < 64) sQ[tid] = gld(P.q + el + tid);
+    const float bt = gld(P.sqrt_beta + c), low_l = gld(P.low + el + c), x_l = ald<BF>(P.X, el + c);
+    const float u_mine = ald<BF>(P.u, (tok0 + tl) * 256 + tid);
+    if (tid < 64) sQ[tid] = ald<BF>(P.q, el + tid);
     float w2c[64], w1c[64];
     gemv_cols_load<64>(P.w2, 256, 0, tid, w2c);
     float dz_ff = 0.f;
@@ -373,7 +377,7 @@ top_bwd_kernel(const TopBwdP P) {
         gst(P.pb_ff + (long)b * 64 + c, dy);
         const float dt = dz_ff * drop_mult1(KARG(TopBwdP, drop_ff), dseed, (uint64_t)(el + c));
         sDT[c] = dt;
-        gst(P.dT + (long)b * 64 + c, dt);
+        ast<BF>(P.dT, (long)b * 64 + c, dt);
     }
     lds_barrier();
     STAMP(1);
@@ -383,7 +387,7 @@ top_bwd_kernel(const TopBwdP P) {
     for (int p = 0; p < 4; ++p) {
         const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
         const long et = (tok0 + min(r, L - 1)) * 64 + c4;            // branch-free: rows past L re-read row L-1, zeroed
-        tx[p] = gld4(P.X + et); tk[p] = gld4(P.k + et); tv[p] = gld4(P.v + et);
+        tx[p] = ald4<BF>(P.X, et); tk[p] = ald4<BF>(P.k, et); tv[p] = ald4<BF>(P.v, et);
         if (r >= L) { tx[p] = f32x4{0, 0, 0, 0}; tk[p] = tx[p]; tv[p] = tx[p]; }
     }
 
@@ -391,7 +395,7 @@ top_bwd_kernel(const TopBwdP P) {
     {
         const float du = gemv_cols_dot<64>(w2c, sDT, 0) * gelu_grad_f(u_mine);
         sDU[tid] = du;
-        gst(P.dU + (long)b * 256 + tid, du);
+        ast<BF>(P.dU, (long)b * 256 + tid, du);
     }
     lds_barrier();
     STAMP(2);
@@ -421,7 +425,7 @@ top_bwd_kernel(const TopBwdP P) {
         const float dO = dza * drop_mult1(KARG(TopBwdP, drop_o), dseed, (uint64_t)(el + c));
         const float dF = dzf * drop_mult1(KARG(TopBwdP, drop_f), dseed, (uint64_t)(el + c));
         sDO[c] = dO;
-        gst(P.dO + (long)b * 64 + c, dO);
+        ast<BF>(P.dO, (long)b * 64 + c, dO);
         const float b2 = bt * bt;
         sDF[c] = (1.0f - b2) * dF;
         sLast[c] = dza + dzf + b2 * dF;
@@ -459,7 +463,7 @@ top_bwd_kernel(const TopBwdP P) {
                 dpd += vv.x * dv.x + vv.y * dv.y + vv.z * dv.z + vv.w * dv.w;
             }
             const long pe = (((long)b * heads + head) * L + tl) * Lp + key;
-            p = gld(P.probs + pe);
+            p = ald<BF>(P.probs, pe);
             mp = drop_mult1(KARG(TopBwdP, drop_p), dseed, (uint64_t)pe);
         }
         const float dp = dpd * mp;
@@ -482,7 +486,7 @@ top_bwd_kernel(const TopBwdP P) {
         for (int j = 0; j < 64; ++j) a4[j & 3] += sDs[head * 64 + j] * sK[j * FS + c];
         acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         sDQ[c] = acc;
-        gst(P.dq + (long)b * 64 + c, acc);
+        ast<BF>(P.dq, (long)b * 64 + c, acc);
         gst(P.pbk + (long)b * 64 + c, sQ[c] * sSum[head]);
         gst(P.pbv + (long)b * 64 + c, sDC[c] * sSum[4 + head]);
     }
@@ -499,8 +503,8 @@ top_bwd_kernel(const TopBwdP P) {
         rk += rk2; rv += rv2;
         const long e = ((long)b * heads + head) * 64 + i;
         const bool mine = i / DH == head;
-        gst(P.rk + e, rk); gst(P.rv + e, rv);
-        gst(P.ak + e, mine ? sQ[i] : 0.f); gst(P.av + e, mine ? sDC[i] : 0.f);
+        ast<BF>(P.rk, e, rk); ast<BF>(P.rv, e, rv);
+        ast<BF>(P.ak, e, mine ? sQ[i] : 0.f); ast<BF>(P.av, e, mine ? sDC[i] : 0.f);
         sQK[o] = gemv_cols_dot<DH>(wkc, sQ, head * DH);
         sCV[o] = gemv_cols_dot<DH>(wvc, sDC, head * DH);
     }
@@ -522,7 +526,7 @@ top_bwd_kernel(const TopBwdP P) {
             for (int h = 0; h < heads; ++h)
                 dx += ld4(sQK + h * 64 + lc) * sDs[h * 64 + j] + ld4(sCV + h * 64 + lc) * sPd[h * 64 + j];
             if (j == tl) dx += ld4(sLast + lc);
-            gst4(P.dX + (tok0 + j) * 64 + lc, dx);
+            ast4<BF>(P.dX, (tok0 + j) * 64 + lc, dx);
         }
     }
     STAMP(15);

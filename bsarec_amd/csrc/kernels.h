@@ -655,9 +655,16 @@ multi_reduce_flat_kernel(const ReduceJob* __restrict__ jobs, const int* __restri
 
 // K9 fused Adam over the flat parameter arena (torch.optim.Adam semantics, src/trainers.py:27-28):
 //   g += wd*w; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// shadow != null (cfg.storage = 1): the rounded parameter also goes to the bf16 mirror, for float4 groups >= shadow_from4
+typedef __bf16 adam_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned adam_pk_bf16(float a, float b) {
+    const adam_bf16x2 r = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, r);
+}
 __global__ void __launch_bounds__(ROW_THREADS)
 adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n4,
-            const uint64_t* __restrict__ state, float b1, float b2, float eps, float wd, float gscale) {
+            const uint64_t* __restrict__ state, float b1, float b2, float eps, float wd, float gscale,
+            unsigned short* __restrict__ shadow, long shadow_from4) {
     const float* f = reinterpret_cast<const float*>(state + 3);
     const float step_size = f[0], bc2s = f[1];
     for (long i = (long)blockIdx.x * ROW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * ROW_THREADS) {
@@ -668,7 +675,21 @@ adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) wi[k] -= step_size * (mi[k] / (sqrtf(vi[k]) / bc2s + eps));
         st4(w + 4 * i, wi); st4(m + 4 * i, mi); st4(v + 4 * i, vi);
+        if (shadow && i >= shadow_from4)
+            *reinterpret_cast<uint2*>(shadow + 4 * i) = make_uint2(adam_pk_bf16(wi.x, wi.y), adam_pk_bf16(wi.z, wi.w));
     }
+}
+
+// fp32 -> bf16 (round to nearest even) for up to six tensors, jobs in the kernarg block: blockIdx.y = tensor
+struct CastJobs6 { const float* src[6]; unsigned short* dst[6]; long n4[6]; };
+__global__ void __launch_bounds__(ROW_THREADS)
+cast_bf16_kernel(const CastJobs6 J) {
+    const float* src = J.src[blockIdx.y];
+    unsigned short* dst = J.dst[blockIdx.y];
+    const long i = (long)blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (i >= J.n4[blockIdx.y]) return;
+    const f32x4 x = ld4(src + 4 * i);
+    *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(adam_pk_bf16(x.x, x.y), adam_pk_bf16(x.z, x.w));
 }
 
 __global__ void __launch_bounds__(ROW_THREADS)

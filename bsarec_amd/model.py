@@ -91,17 +91,24 @@ class _Plan:
         self.ws.zero_()
         self.batch = batch
         self.handle = C.c_void_p()
+        self.bf16 = bool(self.cfg.storage)
         pt, gt = model._tensor_struct(model._arena), model._tensor_struct(model._garena)
+        st = model._tensor_struct(model._shadow_arena()) if self.bf16 else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         L.check(lib.bsarec_plan_create(C.byref(self.handle), C.byref(self.cfg), C.byref(pt), C.byref(gt),
+                                       C.byref(st) if st is not None else None,
                                        self.ws.data_ptr(), nbytes, model._state.data_ptr(),
                                        model._twiddle.data_ptr(), stream), "bsarec_plan_create")
         self.lib = lib
 
     def view(self, buf: int, layer: int, shape) -> torch.Tensor:
+        """A workspace buffer as a tensor: fp32, or bfloat16 where the plan stores it so (cfg.storage = 1)."""
         off = self.lib.bsarec_buffer_offset(self.handle, buf, layer)
         if off < 0:
             raise IndexError("no such buffer")
+        if self.lib.bsarec_buffer_is_bf16(self.handle, buf, layer):
+            n = int(np.prod(shape)) * 2
+            return self.ws[off:off + n].view(torch.bfloat16).view(*shape)
         n = int(np.prod(shape)) * 4
         return self.ws[off:off + n].view(torch.float32).view(*shape)
 
@@ -205,6 +212,26 @@ class BSARecModel(nn.Module):
         self._twiddle = _twiddle(self.args.max_seq_length).to(arena.device)
         self._plans = {}
         self._adam = None
+        self._shadow = None               # bf16 mirror of the arena (plans with storage = 1), allocated on first use
+        self._shadow_stale = True
+
+    def _shadow_arena(self):
+        if self._shadow is None:
+            self._shadow = self._arena.to(torch.bfloat16)
+            self._shadow_stale = True
+        return self._shadow
+
+    def _refresh_shadow(self, plan, force=False):
+        """bf16 storage: the MFMA products read a bf16 shadow of the Linear weights.  The fused Adam keeps it current;
+        after anything else that changes the fp32 masters (load_state_dict, init, an external optimiser) it is rebuilt."""
+        if plan.bf16 and (force or self._shadow_stale):
+            L.check(plan.lib.bsarec_shadow_refresh(plan.handle, self._stream()), "bsarec_shadow_refresh")
+            self._shadow_stale = False
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._shadow_stale = True
+        return out
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -238,10 +265,10 @@ class BSARecModel(nn.Module):
     # ---- C ABI plumbing -----------------------------------------------------------------------
     def _tensor_struct(self, arena) -> L.Tensors:
         t = L.Tensors()
-        base = arena.data_ptr()
+        base, esz = arena.data_ptr(), arena.element_size()       # fp32 arenas, or the bf16 shadow (same element offsets)
 
         def ptr(key):
-            return base + 4 * self._slices[key][0]
+            return base + esz * self._slices[key][0]
         for f, key in L.TOP_KEYS.items():
             setattr(t, f, ptr(key))
         for l in range(self.args.num_hidden_layers):
@@ -286,6 +313,10 @@ class BSARecModel(nn.Module):
         if new_step:
             L.check(lib.bsarec_step_begin(plan.handle, st), "bsarec_step_begin")
             self._step_begun = True          # the counter now holds a value in use (see _fresh_step_counter)
+        # the eager API may follow an update of the masters this module cannot see (torch.optim over model.parameters()):
+        # always rebuild the bf16 shadow here (storage = 1 only; one small launch per layer)
+        self._refresh_shadow(plan, force=True)
+        self._shadow_stale = True
         # last_only: the caller consumes position L-1 of the last layer only (loss / logits / backward)
         fwd = lib.bsarec_forward_last if last_only else lib.bsarec_forward
         L.check(fwd(plan.handle, ids.data_ptr(), 1 if train else 0, st), "bsarec_forward")
@@ -315,7 +346,7 @@ class BSARecModel(nn.Module):
         plan = self._run_forward(input_ids, train=self.training, new_step=self.training)
         B, Lq, d = input_ids.shape[0], self.args.max_seq_length, self.args.hidden_size
         if all_sequence_output:
-            return [plan.view(L.BUF_LAYER_OUT, l, (B, Lq, d)).clone() for l in range(self.args.num_hidden_layers + 1)]
+            return [plan.view(L.BUF_LAYER_OUT, l, (B, Lq, d)).float().clone() for l in range(self.args.num_hidden_layers + 1)]
         return plan.view(L.BUF_LAYER_OUT, self.args.num_hidden_layers, (B, Lq, d)).clone()
 
     def predict(self, input_ids, user_ids=None, all_sequence_output=False):
@@ -346,6 +377,15 @@ class BSARecModel(nn.Module):
                           m=torch.zeros_like(self._arena), v=torch.zeros_like(self._arena))
         self._state[2] = 0
 
+    def _adam_struct(self, grad_scale: float = 1.0) -> L.Adam:
+        a = self._adam
+        s = L.Adam(self._arena.data_ptr(), self._garena.data_ptr(), a["m"].data_ptr(), a["v"].data_ptr(), self._numel,
+                   a["lr"], a["b1"], a["b2"], a["eps"], a["wd"], float(grad_scale), None, 0)
+        if self._shadow is not None:           # keep the bf16 shadow of everything behind the item table current
+            s.shadow_bf16 = self._shadow.data_ptr()
+            s.shadow_from = self._slices["position_embeddings.weight"][0]
+        return s
+
     def train_step(self, input_ids, answers) -> torch.Tensor:
         """step_begin + forward + loss + backward + Adam in one C call (src/trainers.py:100-107).
         Returns a view of the device loss scalar (no host sync)."""
@@ -354,10 +394,9 @@ class BSARecModel(nn.Module):
         ids = input_ids.to(device=self._arena.device, dtype=torch.int64).contiguous()
         ans = answers.to(device=self._arena.device, dtype=torch.int64).contiguous()
         plan = self._plan(ids.shape[0])
-        a = self._adam
-        L.check(plan.lib.bsarec_train_step(plan.handle, ids.data_ptr(), ans.data_ptr(), self._arena.data_ptr(),
-                                           self._garena.data_ptr(), a["m"].data_ptr(), a["v"].data_ptr(), self._numel,
-                                           a["lr"], a["b1"], a["b2"], a["eps"], a["wd"], self._stream()),
+        self._refresh_shadow(plan)
+        ad = self._adam_struct()
+        L.check(plan.lib.bsarec_train_step(plan.handle, ids.data_ptr(), ans.data_ptr(), C.byref(ad), self._stream()),
                 "bsarec_train_step")
         self._step_begun = True
         plan._ids_keepalive, plan._ans_keepalive = ids, ans
@@ -374,13 +413,12 @@ class BSARecModel(nn.Module):
             dev = self._arena.device
             plan.ids_buf = torch.zeros((batch, self.args.max_seq_length), dtype=torch.int64, device=dev)
             plan.ans_buf = torch.zeros((batch,), dtype=torch.int64, device=dev)
-        a = self._adam
         self._fresh_step_counter(plan)
+        self._refresh_shadow(plan)
+        ad = self._adam_struct()
         L.check(plan.lib.bsarec_train_step_indexed(
             plan.handle, table.data_ptr(), answers_table.data_ptr(), perm.data_ptr(), perm.shape[0], cursor.data_ptr(),
-            plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), self._arena.data_ptr(), self._garena.data_ptr(),
-            a["m"].data_ptr(), a["v"].data_ptr(), self._numel, a["lr"], a["b1"], a["b2"], a["eps"], a["wd"],
-            self._stream()), "bsarec_train_step_indexed")
+            plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), C.byref(ad), self._stream()), "bsarec_train_step_indexed")
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
     def grad_step_indexed(self, table, answers_table, perm, cursor, batch: int, tick_adam: bool = False) -> torch.Tensor:
@@ -393,6 +431,7 @@ class BSARecModel(nn.Module):
             plan.ids_buf = torch.zeros((batch, self.args.max_seq_length), dtype=torch.int64, device=dev)
             plan.ans_buf = torch.zeros((batch,), dtype=torch.int64, device=dev)
         self._fresh_step_counter(plan)
+        self._refresh_shadow(plan)
         L.check(plan.lib.bsarec_grad_step_indexed(
             plan.handle, table.data_ptr(), answers_table.data_ptr(), perm.data_ptr(), perm.shape[0], cursor.data_ptr(),
             plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), self._adam["lr"] if tick_adam else 0.0,
@@ -402,16 +441,9 @@ class BSARecModel(nn.Module):
 
     def adam_step(self, grad_scale: float = 1.0, tick: bool = True):
         """Fused Adam over the flat arenas (after an external gradient all-reduce)."""
-        a = self._adam
-        if not tick:
-            L.check(L.load().bsarec_adam_apply(self._arena.data_ptr(), self._garena.data_ptr(), a["m"].data_ptr(),
-                                               a["v"].data_ptr(), self._numel, self._state.data_ptr(), a["b1"], a["b2"],
-                                               a["eps"], a["wd"], float(grad_scale), self._stream()), "bsarec_adam_apply")
-            return
-        L.check(L.load().bsarec_adam_step(self._arena.data_ptr(), self._garena.data_ptr(), a["m"].data_ptr(),
-                                          a["v"].data_ptr(), self._numel, self._state.data_ptr(), a["lr"], a["b1"],
-                                          a["b2"], a["eps"], a["wd"], float(grad_scale), self._stream()),
-                "bsarec_adam_step")
+        ad = self._adam_struct(grad_scale)
+        fn = L.load().bsarec_adam_step if tick else L.load().bsarec_adam_apply
+        L.check(fn(C.byref(ad), self._state.data_ptr(), self._stream()), "bsarec_adam_step" if tick else "bsarec_adam_apply")
 
     def grad_views(self) -> "OrderedDict[str, torch.Tensor]":
         return OrderedDict((k, self._garena[o:o + n].view(shp)) for k, (o, n, shp) in self._slices.items())

@@ -110,10 +110,20 @@ size_t bsarec_workspace_bytes(const bsarec_config_t *cfg);
 /* Build a launch plan.  `params`/`grads` hold device pointers (copied into the plan); `workspace`
  * must hold bsarec_workspace_bytes(cfg) bytes, 256-byte aligned; `twiddle` is the float[2L] table
  * (cos, sin)(2 pi j / L) built on the host in double precision.  Enqueues one small H2D copy of the
- * reduction job table on `stream`.  Replaces: model construction wiring of src/model/bsarec.py:8-14. */
+ * reduction job table on `stream` and waits for it (the one synchronising call of the training path).
+ * `shadow` (cfg.storage = 1 only, else null): the same tensor set as `params` but as bf16 arrays (uint16_t behind the
+ * float* fields) -- the bf16 shadow of the fp32 masters that the MFMA products read; only the six Linear weights of
+ * every layer are used.  The caller keeps it current: bsarec_shadow_refresh after it changes the masters itself, or
+ * bsarec_adam_t.shadow_bf16 so that the fused Adam writes both.
+ * Replaces: model construction wiring of src/model/bsarec.py:8-14. */
 int bsarec_plan_create(bsarec_plan_t **out, const bsarec_config_t *cfg, const bsarec_tensors_t *params,
-                       const bsarec_tensors_t *grads, void *workspace, size_t workspace_bytes,
-                       void *state, const float *twiddle, void *stream);
+                       const bsarec_tensors_t *grads, const bsarec_tensors_t *shadow, void *workspace,
+                       size_t workspace_bytes, void *state, const float *twiddle, void *stream);
+/* cfg.storage = 1: bf16 shadow <- fp32 masters for the Linear weights of every layer (one launch per layer). */
+int bsarec_shadow_refresh(bsarec_plan_t *plan, void *stream);
+/* Element type of a named workspace buffer under this plan: 0 = fp32, 1 = bf16 (cfg.storage = 1: every saved
+ * activation of the block stack except the last layer's output; logits, loss and the statistics stay fp32). */
+int bsarec_buffer_is_bf16(const bsarec_plan_t *plan, int buffer, int layer);
 void bsarec_plan_destroy(bsarec_plan_t *plan);
 
 /* Byte offset of a named buffer inside the workspace, or -1. */
@@ -155,17 +165,27 @@ int bsarec_logits(bsarec_plan_t *plan, void *stream);
  * accumulated).  Must follow bsarec_forward(train as given there) + bsarec_loss on the same plan. */
 int bsarec_backward(bsarec_plan_t *plan, void *stream);
 
-/* torch.optim.Adam step (src/trainers.py:27-28,107) over flat arenas of n floats (n % 4 == 0):
- * g is scaled by grad_scale first (1/world_size after a summing all-reduce). */
-int bsarec_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, void *state,
-                     float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                     void *stream);
+/* torch.optim.Adam (src/trainers.py:27-28,107) over flat arenas: one struct for every entry point that updates. */
+typedef struct {
+    float *params;            /* [n] fp32 master parameters (n % 4 == 0) */
+    const float *grads;       /* [n] gradients (written by bsarec_backward through the plan's `grads` pointers) */
+    float *exp_avg, *exp_avg_sq;   /* [n] Adam moments */
+    long n;
+    float lr, beta1, beta2, eps, weight_decay;
+    float grad_scale;         /* g is scaled by this first (1/world_size after a summing all-reduce; else 1) */
+    void *shadow_bf16;        /* null, or bf16[n] mirror of params (cfg.storage = 1): the update also writes the rounded */
+    long shadow_from;         /*   parameter to shadow_bf16[i] for i >= shadow_from (the tensors after the item table) */
+} bsarec_adam_t;
+
+/* Advance Adam's t / bias corrections in `state`, then update. */
+int bsarec_adam_step(const bsarec_adam_t *adam, void *state, void *stream);
+/* The parameter update alone (t and the bias corrections were already advanced by bsarec_grad_step_indexed(lr > 0)). */
+int bsarec_adam_apply(const bsarec_adam_t *adam, void *state, void *stream);
 
 /* Trainer.iteration's per-batch body (src/trainers.py:100-107) in one call:
  * step_begin + forward(train) + loss + backward + Adam. */
-int bsarec_train_step(bsarec_plan_t *plan, const int64_t *ids, const int64_t *answers, float *params_flat,
-                      const float *grads_flat, float *exp_avg, float *exp_avg_sq, long n, float lr, float beta1,
-                      float beta2, float eps, float weight_decay, void *stream);
+int bsarec_train_step(bsarec_plan_t *plan, const int64_t *ids, const int64_t *answers, const bsarec_adam_t *adam,
+                      void *stream);
 
 /* Device-side batch assembly from a resident sample table (replaces RandomSampler + DataLoader collation,
  * src/dataset.py:207-211): ids_out[b,:] = table[perm[*cursor + b], :], answers_out[b] = answers_table[perm[*cursor + b]].
@@ -174,25 +194,22 @@ int bsarec_gather_batch(const int64_t *table, const int64_t *answers_table, cons
                         const void *cursor, int B, int L, int64_t *ids_out, int64_t *answers_out, void *stream);
 
 /* bsarec_train_step fed from the resident table: the embedding kernel assembles the batch at *cursor (and fills
- * ids_buf / answers_buf), forward + loss + backward + Adam; the Adam kernel's last block closes the step (mean loss,
- * forward-step index += 1, *cursor += B).  A captured graph of this call
- * replays a whole epoch with no host work. */
+ * ids_buf / answers_buf), forward + loss + backward + Adam; the closing block of the gradient reduction ends the step
+ * (mean loss, forward-step index += 1, *cursor += B).  A captured graph of this call replays a whole epoch with no
+ * host work.  The dropout step counter is used as it stands and advanced at the END (bsarec_train_step /
+ * bsarec_step_begin advance it BEFORE use): call bsarec_step_begin once between a begin-style step and this one. */
 int bsarec_train_step_indexed(bsarec_plan_t *plan, const int64_t *table, const int64_t *answers_table,
                               const int64_t *perm, long n_samples, void *cursor, int64_t *ids_buf, int64_t *answers_buf,
-                              float *params_flat, const float *grads_flat, float *exp_avg, float *exp_avg_sq, long n,
-                              float lr, float beta1, float beta2, float eps, float weight_decay, void *stream);
+                              const bsarec_adam_t *adam, void *stream);
 
-/* The data-parallel half of the above: gather + forward + loss + backward (no Adam).  The caller then all-reduces the
- * flat gradient arena (RCCL) and calls bsarec_adam_step(grad_scale = 1/world) -- or, when lr > 0 is given here, the
- * step's closing block also advances Adam's t and publishes the bias corrections, and the caller follows the
- * all-reduce with bsarec_adam_apply (one launch fewer per step).  lr <= 0: no Adam bookkeeping here. */
+/* The data-parallel half of the above: gather + forward + loss + backward (no Adam).  The caller then exchanges the
+ * flat gradient arena (RCCL all-reduce, or the peer-to-peer read of bsarec_comm.h) and calls
+ * bsarec_adam_step(grad_scale = 1/world) -- or, when lr > 0 is given here, the step's closing block also advances
+ * Adam's t and publishes the bias corrections, and the caller follows the exchange with bsarec_adam_apply (one launch
+ * fewer per step).  lr <= 0: no Adam bookkeeping here. */
 int bsarec_grad_step_indexed(bsarec_plan_t *plan, const int64_t *table, const int64_t *answers_table,
                              const int64_t *perm, long n_samples, void *cursor, int64_t *ids_buf, int64_t *answers_buf,
                              float lr, float beta1, float beta2, void *stream);
-/* The parameter update of bsarec_adam_step alone (t and the bias corrections were already advanced by
- * bsarec_grad_step_indexed(lr > 0)). */
-int bsarec_adam_apply(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, void *state,
-                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, void *stream);
 
 /* Evaluation branch of Trainer.iteration (src/trainers.py:134): scores[b][indices[j]] = 0 (not -inf) for every item j
  * of the CSR row indptr[users[b]] .. indptr[users[b] + 1] -- the items user b has already seen (the reference's
