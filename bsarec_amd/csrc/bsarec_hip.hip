@@ -1022,7 +1022,10 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                 GemmP g = gemm_defaults(sp[i].M, sp[i].N, last_only ? B : T);
                 g.lda = sp[i].lda; g.ldb = sp[i].ldb; g.A[0] = sp[i].A; g.B[0] = sp[i].B; g.nsplit = ns; g.kchunk = p->kchunk;
                 if (last_only) {
-                    g.A[0] += (long)(L - 1) * sp[i].lda; g.B[0] += (long)(L - 1) * sp[i].ldb;
+                    // row L-1 of every sequence (element offsets: the operands are bf16 tensors under storage = 1)
+                    const long esz = p->bf ? 2 : 4;
+                    g.A[0] = (const float*)((const char*)g.A[0] + (long)(L - 1) * sp[i].lda * esz);
+                    g.B[0] = (const float*)((const char*)g.B[0] + (long)(L - 1) * sp[i].ldb * esz);
                     g.lda *= L; g.ldb *= L;
                     g.kchunk = (int)rup(cdiv(B, ns), GEMM_BK);           // slices beyond ceil(B / kchunk) write zero slabs
                     if (top_pruned) {                                    // gradient rows come compact ([B][M]) from top_bwd_kernel

@@ -4,9 +4,10 @@ The oracle is fp32 (the reference cannot run in bf16 on CPU): the bf1
 oracle / the reference's fp32 golden vectors at the looser gates stated here.  Where the gates come from: bf16 keeps 8
 significant bits (relative rounding error 2^-9 = 2e-3 per stored value); every saved activation, every inter-block
 gradient and the Linear weights are rounded once, products accumulate in fp32, LayerNorm / softmax / loss / Adam stay
-fp32.  Measured on MI355X (r02): logits rel-Linf 2-4e-3 of the largest logit, loss rel 1-3e-4, parameter gradients
-rel-L2 0.5-2 %.  Gates (with margin): logits <= 1e-2 rel-Linf, loss <= 2e-3 rel, gradients <= 4e-2 rel-L2
-(key.bias, whose true gradient is 0: <= 1e-4 abs).  The fp32 path keeps the north star's gate (logits <= 1e-3)."""
+fp32.  Measured on MI355X (r02, gpurun_out/r02b): logits rel-Linf 1.5e-3 of the largest logit, loss rel 6e-7 .. 1.8e-5,
+parameter gradients rel-L2 median 2.6e-3, worst 7.1e-3 (block 0 query / key weights).  Gates (about 3x the measured
+worst): logits <= 5e-3 rel-Linf, loss <= 5e-4 rel, gradients <= 2e-2 rel-L2 (key.bias, whose true gradient is 0:
+<= 1e-4 abs).  The fp32 path keeps the north star's gate (logits <= 1e-3)."""
 import argparse
 import json
 import os
@@ -19,7 +20,7 @@ from conftest import GOLDEN, load_e2e, rel_l2
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-LOGITS_GATE, LOSS_GATE, GRAD_GATE, OUT_GATE = 1e-2, 2e-3, 4e-2, 3e-2
+LOGITS_GATE, LOSS_GATE, GRAD_GATE, OUT_GATE = 5e-3, 5e-4, 2e-2, 3e-2
 
 
 def make_args(cfg, **kw):
