@@ -99,7 +99,17 @@ class Adam(C.Structure):
     """bsarec_adam_t"""
     _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("n", C.c_long), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("shadow_bf16", C.c_void_p), ("shadow_from", C.c_long)]
+                ("weight_decay", C.c_float), ("grad_scale", C.c_float), ("shadow_bf16", C.c_void_p), ("shadow_from", C.c_long),
+                ("grads2", C.c_void_p), ("grads2_n", C.c_long), ("n_grad_srcs", C.c_int), ("grad_srcs", C.c_void_p * 8)]
+
+
+class Comm(C.Structure):
+    """bsarec_comm_t (include/bsarec_comm.h)"""
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("flags", C.c_void_p * 8), ("epoch", C.c_void_p),
+                ("error", C.c_void_p), ("timeout_ms", C.c_int)]
+
+
+HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)          # bsarec_hook_t
 
 
 EXPORTS = {
@@ -108,6 +118,7 @@ EXPORTS = {
     "bsarec_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config), C.POINTER(Tensors), C.POINTER(Tensors),
                                      C.POINTER(Tensors), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_shadow_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsarec_plan_set_dense_grad_hook": (C.c_int, [C.c_void_p, HOOK, C.c_void_p, C.c_void_p]),
     "bsarec_buffer_is_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bsarec_plan_destroy": (None, [C.c_void_p]),
     "bsarec_buffer_offset": (C.c_long, [C.c_void_p, C.c_int, C.c_int]),
@@ -138,6 +149,16 @@ EXPORTS = {
     "bsarec_profile_event_overhead": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
 }
 
+# include/bsarec_comm.h
+COMM_EXPORTS = {
+    "bsarec_comm_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "bsarec_comm_free": (C.c_int, [C.c_void_p]),
+    "bsarec_comm_export": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "bsarec_comm_import": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bsarec_comm_release": (C.c_int, [C.c_void_p]),
+    "bsarec_comm_barrier": (C.c_int, [C.POINTER(Comm), C.c_void_p]),
+}
+
 _lib = None
 
 
@@ -163,7 +184,7 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m bsarec_amd.build` (hipcc, gfx950). "
             "bsarec_amd has no fallback path.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in EXPORTS.items():
+    for name, (res, args) in list(EXPORTS.items()) + list(COMM_EXPORTS.items()):
         fn = getattr(lib, name)       # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args

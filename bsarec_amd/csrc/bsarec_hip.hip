@@ -5,6 +5,7 @@
 #include "fused_layer.h"
 #include "dw_direct.h"
 #include "fused_top.h"
+#include "comm.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -144,6 +145,8 @@ struct bsarec_plan {
     int top_slabs; bool embed_in_block, direct_dw;
     ProfState prof;
     long long* stamps = nullptr;             // diagnostic stamp buffer (bsarec_debug_stamps)
+    bsarec_hook_t dense_hook = nullptr; void* dense_hook_user = nullptr;   // bsarec_plan_set_dense_grad_hook
+    float* lookup_grad = nullptr;            // target of the embedding scatter when the dense dE is exchanged early
 };
 static ProfState* prof_of(bsarec_plan* p) { return &p->prof; }
 struct PlanScope {                           // marks the plan a C call works on for this thread (nesting-safe)
@@ -404,6 +407,12 @@ extern "C" long bsarec_buffer_offset(const bsarec_plan_t* p, int buffer, int lay
         default: return -1;
     }
     return (long)((const char*)ptr - p->ws);
+}
+
+extern "C" int bsarec_plan_set_dense_grad_hook(bsarec_plan_t* p, bsarec_hook_t hook, void* user, float* lookup_grad) {
+    if (!p) return -10;
+    p->dense_hook = hook; p->dense_hook_user = user; p->lookup_grad = lookup_grad;
+    return 0;
 }
 
 extern "C" int bsarec_buffer_is_bf16(const bsarec_plan_t* p, int buffer, int layer) {
@@ -897,6 +906,8 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
             RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(G.B, nox, G.EB, nullptr, 1, s)));
         }
     }
+    // the dense item-table gradient is complete (enqueued): a data-parallel host may start exchanging it now
+    if (p->dense_hook && !g_dry) p->dense_hook(p->dense_hook_user, stream);
     float* dY = (N & 1) ? p->dXb : p->dXa;       // gradient w.r.t. X[l+1]; ping-pong so that dX[0] lands in dXa
     if (!p->fused) {      // the fused top-layer backward synthesises this gradient from the slabs itself
         LAUNCH(dlast_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, p->dlast_slab,
@@ -1110,7 +1121,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
             }
             const int sb = cdiv(T, CHUNK);
             LAUNCH(embed_bwd_kernel<LPR>, dim3(sb + L * p->pos_slices), dim3(ROW_THREADS), smem, se, p->dz, p->ids32, B, L, d,
-                   p->G.item_emb, p->part_pos, sb);
+                   p->lookup_grad ? p->lookup_grad : p->G.item_emb, p->part_pos, sb);
             HIPCHK(hipGetLastError());
         });
         // ---- ONE deterministic second-stage reduction for every split-K slab and LayerNorm / beta partial
@@ -1138,6 +1149,9 @@ static TickP make_tick(void* state, int adam, float lr, float b1, float b2, cons
 static int adam_check(const bsarec_adam_t* a) {
     if (!a || !a->params || !a->grads || !a->exp_avg || !a->exp_avg_sq || a->n <= 0 || (a->n & 3)) return -10;
     if (a->shadow_bf16 && (a->shadow_from < 0 || (a->shadow_from & 3))) return -10;
+    if (a->grads2 && (a->grads2_n < 0 || a->grads2_n > a->n || (a->grads2_n & 3))) return -10;
+    if (a->n_grad_srcs < 0 || a->n_grad_srcs > 8) return -10;
+    for (int r = 0; r < a->n_grad_srcs; ++r) if (!a->grad_srcs[r]) return -10;
     return 0;
 }
 
@@ -1145,9 +1159,14 @@ static int adam_launch(const bsarec_adam_t& a, void* state, hipStream_t s) {
     const long n4 = a.n / 4;
     int blocks = cdiv(n4, ROW_THREADS);
     if (blocks > 2048) blocks = 2048;
+    GradSrcs S;
+    memset(&S, 0, sizeof(S));
+    S.nsrc = a.n_grad_srcs;
+    for (int r = 0; r < a.n_grad_srcs; ++r) S.src[r] = a.grad_srcs[r];
+    S.g2 = a.grads2; S.n2_4 = a.grads2 ? a.grads2_n / 4 : 0;
     LAUNCH(adam_kernel, dim3(blocks), dim3(ROW_THREADS), 0, s, a.params, a.grads, a.exp_avg, a.exp_avg_sq, n4,
            (const uint64_t*)state, a.beta1, a.beta2, a.eps, a.weight_decay, a.grad_scale, (unsigned short*)a.shadow_bf16,
-           a.shadow_bf16 ? a.shadow_from / 4 : n4);
+           a.shadow_bf16 ? a.shadow_from / 4 : n4, S);
     return (int)hipGetLastError();
 }
 

@@ -661,14 +661,38 @@ __device__ __forceinline__ unsigned adam_pk_bf16(float a, float b) {
     const adam_bf16x2 r = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, r);
 }
+// Gradient sources of the data-parallel step (bsarec_adam_t): g = grads (+ grads2 on the first n2 float4 groups, zeroed
+// after use), or the sum over nsrc arenas in index order -- the one-shot peer-to-peer exchange: srcs[r] is rank r's
+// arena, IPC-mapped over xGMI except the local one; read with system-scope (sc0 sc1) loads so that no cache of THIS GPU
+// can serve a line from the previous step.
+struct GradSrcs { int nsrc; const float* src[8]; float* g2; long n2_4; };
+__device__ __forceinline__ f32x4 ld4_sys(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 __global__ void __launch_bounds__(ROW_THREADS)
 adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n4,
             const uint64_t* __restrict__ state, float b1, float b2, float eps, float wd, float gscale,
-            unsigned short* __restrict__ shadow, long shadow_from4) {
+            unsigned short* __restrict__ shadow, long shadow_from4, const GradSrcs S) {
     const float* f = reinterpret_cast<const float*>(state + 3);
     const float step_size = f[0], bc2s = f[1];
     for (long i = (long)blockIdx.x * ROW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * ROW_THREADS) {
-        f32x4 wi = ld4(w + 4 * i), gi = ld4(g + 4 * i) * gscale, mi = ld4(m + 4 * i), vi = ld4(v + 4 * i);
+        f32x4 gi;
+        if (S.nsrc > 0) {
+            f32x4 part[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (r < S.nsrc) part[r] = ld4_sys(S.src[r] + 4 * i);     // all peers in flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            gi = part[0];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) if (r < S.nsrc) gi += part[r];                            // rank order on every rank
+        } else {
+            gi = ld4(g + 4 * i);
+            if (S.g2 && i < S.n2_4) { gi += ld4(S.g2 + 4 * i); st4(S.g2 + 4 * i, f32x4{0, 0, 0, 0}); }
+        }
+        gi = gi * gscale;
+        f32x4 wi = ld4(w + 4 * i), mi = ld4(m + 4 * i), vi = ld4(v + 4 * i);
         if (wd != 0.f) gi += wd * wi;
         mi = b1 * mi + (1.0f - b1) * gi;
         vi = b2 * vi + (1.0f - b2) * gi * gi;

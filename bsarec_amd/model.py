@@ -67,7 +67,7 @@ def _twiddle(Lq: int) -> torch.Tensor:
 class _Plan:
     """One launch plan (fixed batch size) + the workspace tensor it carves."""
 
-    def __init__(self, model: "BSARecModel", batch: int):
+    def __init__(self, model: "BSARecModel", batch: int, garena=None, share_ws_with: "Optional[_Plan]" = None):
         lib = L.load()
         a = model.args
         self.cfg = L.Config(batch, a.max_seq_length, a.hidden_size, a.num_attention_heads, a.num_hidden_layers,
@@ -85,14 +85,19 @@ class _Plan:
                              "L <= 256, hidden <= 256 and % 4 == 0, head size % 4 == 0, cutoff_bins*hidden <= 8192; "
                              "storage = bf16 needs the fused shape hidden = 64, L <= 64)")
         dev = model._arena.device
-        self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-        off = (-self.ws.data_ptr()) % 256
-        self.ws = self.ws[off:off + nbytes]
-        self.ws.zero_()
+        if share_ws_with is not None:                   # a second plan over the same workspace (never run concurrently):
+            self.ws = share_ws_with.ws                  # the other gradient arena of the peer-to-peer exchange
+            assert self.ws.numel() >= nbytes
+        else:
+            self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            off = (-self.ws.data_ptr()) % 256
+            self.ws = self.ws[off:off + nbytes]
+            self.ws.zero_()
         self.batch = batch
         self.handle = C.c_void_p()
         self.bf16 = bool(self.cfg.storage)
-        pt, gt = model._tensor_struct(model._arena), model._tensor_struct(model._garena)
+        self.garena = model._garena if garena is None else garena
+        pt, gt = model._tensor_struct(model._arena), model._tensor_struct(self.garena)
         st = model._tensor_struct(model._shadow_arena()) if self.bf16 else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         L.check(lib.bsarec_plan_create(C.byref(self.handle), C.byref(self.cfg), C.byref(pt), C.byref(gt),
@@ -214,6 +219,38 @@ class BSARecModel(nn.Module):
         self._adam = None
         self._shadow = None               # bf16 mirror of the arena (plans with storage = 1), allocated on first use
         self._shadow_stale = True
+        self._garena_alt = None           # second gradient arena (peer-to-peer exchange: arenas alternate by step parity)
+        self._lookup = None               # [V*d] lookup-path rows of the item-table gradient (bucketed exchange)
+        self._dense_hook = None
+
+    def use_grad_arenas(self, arenas):
+        """Data parallel, ``p2p`` exchange: gradients are written into caller-provided arenas (IPC-exported memory);
+        ``arenas[parity]`` is the target of the steps with that parity."""
+        assert all(a.numel() == self._numel and a.dtype == torch.float32 for a in arenas)
+        self._garena, self._garena_alt = arenas[0], arenas[1]
+        self._garena.zero_(); self._garena_alt.zero_()
+        self._plans = {}
+
+    def enable_lookup_grad(self):
+        """Data parallel, bucketed exchange: one buffer [gradient arena | lookup rows of the item table] so that the
+        second bucket (encoder gradients + lookup rows) is one contiguous message."""
+        vd = self._slices["item_embeddings.weight"][1]
+        self._gbuf = torch.zeros(self._numel + vd, dtype=torch.float32, device=self._arena.device)
+        self._garena, self._lookup = self._gbuf[:self._numel], self._gbuf[self._numel:]
+        self._plans = {}
+
+    def set_dense_grad_hook(self, fn):
+        """``fn(stream)`` is called as soon as the dense item-table gradient is enqueued (bsarec_plan_set_dense_grad_hook);
+        applies to the plans created from now on and to the existing ones."""
+        self._dense_hook_py = fn
+        self._dense_hook = L.HOOK(lambda user, stream: fn(stream)) if fn is not None else None
+        for plan in self._plans.values():
+            self._install_hook(plan)
+
+    def _install_hook(self, plan):
+        lk = self._lookup.data_ptr() if (self._lookup is not None and plan.garena is self._garena) else None
+        hook = self._dense_hook if self._dense_hook is not None else L.HOOK(0)
+        L.check(plan.lib.bsarec_plan_set_dense_grad_hook(plan.handle, hook, None, lk), "bsarec_plan_set_dense_grad_hook")
 
     def _shadow_arena(self):
         if self._shadow is None:
@@ -290,15 +327,20 @@ class BSARecModel(nn.Module):
         s = (int(seed) ^ (rank * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
         self._state[0] = s
 
-    def _plan(self, batch: int) -> _Plan:
+    def _plan(self, batch: int, parity: int = 0) -> _Plan:
         self._require_gpu()
         opts = L.default_options()
         opts.update(self.options)
-        key = (batch, str(self._arena.device), tuple(sorted(opts.items())))
+        key = (batch, str(self._arena.device), tuple(sorted(opts.items())), parity)
         if key not in self._plans:
             if int(self._state[0].item()) == 0:
                 self.set_seed(self._seed)
-            self._plans[key] = _Plan(self, batch)
+            if parity == 0:
+                self._plans[key] = _Plan(self, batch)
+            else:                                          # same workspace, the other gradient arena
+                self._plans[key] = _Plan(self, batch, garena=self._garena_alt, share_ws_with=self._plan(batch, 0))
+            if self._lookup is not None or self._dense_hook is not None:
+                self._install_hook(self._plans[key])
         return self._plans[key]
 
     def _stream(self):
@@ -377,10 +419,16 @@ class BSARecModel(nn.Module):
                           m=torch.zeros_like(self._arena), v=torch.zeros_like(self._arena))
         self._state[2] = 0
 
-    def _adam_struct(self, grad_scale: float = 1.0) -> L.Adam:
+    def _adam_struct(self, grad_scale: float = 1.0, grad_srcs=None) -> L.Adam:
         a = self._adam
         s = L.Adam(self._arena.data_ptr(), self._garena.data_ptr(), a["m"].data_ptr(), a["v"].data_ptr(), self._numel,
                    a["lr"], a["b1"], a["b2"], a["eps"], a["wd"], float(grad_scale), None, 0)
+        if self._lookup is not None:            # bucketed exchange: the lookup rows of the item table sit in their own buffer
+            s.grads2, s.grads2_n = self._lookup.data_ptr(), self._lookup.numel()
+        if grad_srcs:                           # peer-to-peer exchange: sum of every rank's arena, in rank order
+            s.n_grad_srcs = len(grad_srcs)
+            for i, p in enumerate(grad_srcs):
+                s.grad_srcs[i] = p
         if self._shadow is not None:           # keep the bf16 shadow of everything behind the item table current
             s.shadow_bf16 = self._shadow.data_ptr()
             s.shadow_from = self._slices["position_embeddings.weight"][0]
@@ -421,11 +469,13 @@ class BSARecModel(nn.Module):
             plan.ids_buf.data_ptr(), plan.ans_buf.data_ptr(), C.byref(ad), self._stream()), "bsarec_train_step_indexed")
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
-    def grad_step_indexed(self, table, answers_table, perm, cursor, batch: int, tick_adam: bool = False) -> torch.Tensor:
+    def grad_step_indexed(self, table, answers_table, perm, cursor, batch: int, tick_adam: bool = False,
+                          parity: int = 0) -> torch.Tensor:
         """Data-parallel half of train_step_indexed: gather + forward + loss + backward into the gradient arena
         (no Adam).  Follow with an all-reduce of ``_garena`` and :meth:`adam_step` -- or, with ``tick_adam``, the step's
-        closing block already advances Adam's t / bias corrections and :meth:`adam_step(tick=False)` applies the update."""
-        plan = self._plan(batch)
+        closing block already advances Adam's t / bias corrections and :meth:`adam_step(tick=False)` applies the update.
+        ``parity`` selects the gradient arena (:meth:`use_grad_arenas`)."""
+        plan = self._plan(batch, parity)
         if not hasattr(plan, "ids_buf"):
             dev = self._arena.device
             plan.ids_buf = torch.zeros((batch, self.args.max_seq_length), dtype=torch.int64, device=dev)
@@ -439,9 +489,10 @@ class BSARecModel(nn.Module):
             "bsarec_grad_step_indexed")
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
-    def adam_step(self, grad_scale: float = 1.0, tick: bool = True):
-        """Fused Adam over the flat arenas (after an external gradient all-reduce)."""
-        ad = self._adam_struct(grad_scale)
+    def adam_step(self, grad_scale: float = 1.0, tick: bool = True, grad_srcs=None):
+        """Fused Adam over the flat arenas (after an external gradient exchange, or -- ``grad_srcs`` -- reading every
+        rank's gradient arena itself)."""
+        ad = self._adam_struct(grad_scale, grad_srcs)
         fn = L.load().bsarec_adam_step if tick else L.load().bsarec_adam_apply
         L.check(fn(C.byref(ad), self._state.data_ptr(), self._stream()), "bsarec_adam_step" if tick else "bsarec_adam_apply")
 

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .data import DeviceBatches
-from .dp import allreduce_sum_
+from .dp import PeerExchange, allreduce_sum_
 from .model import BSARecModel
 
 
@@ -59,16 +59,68 @@ class Trainer:
         self._graphs = {}
         self._seen_cache = {}
         self._sync_replicas()
+        self._setup_exchange()
+
+    # ---- data-parallel gradient exchange (bsarec_amd/dp.py) ------------------------------------------
+    def _setup_exchange(self):
+        self._px, self._side, self._b1_done, self._nsteps = None, None, None, 0
+        if not self.dp:
+            self.exchange = "none"
+            return
+        m = self.model
+        backend = torch.distributed.get_backend(self.pg)
+        self._backend = backend
+        mode = self.exchange
+        if mode == "auto":
+            # RCCL collectives need the nccl backend; the peer-to-peer read needs > 1 rank, one node and working IPC
+            # mappings (proved by a self-test on the hardware it runs on; any failure falls back on every rank alike)
+            mode = "p2p" if self.world > 1 else "rccl"
+        if mode == "p2p":
+            self._px = PeerExchange.create(m._numel, self.pg, self.device, self.logger)
+            if self._px is None:
+                mode = "rccl_bucketed" if backend == "nccl" else "rccl"
+            else:
+                m.use_grad_arenas(self._px.arenas)
+        if mode == "rccl_bucketed":
+            m.enable_lookup_grad()
+            self._side = torch.cuda.Stream(self.device)
+            self._vd = m._lookup.numel()
+        self.exchange = mode
+
+    def _dense_hook(self, stream):
+        """Called by the library as soon as the dense item-table gradient is enqueued: all-reduce it on the side stream,
+        under the encoder backward that the main stream goes on to enqueue."""
+        cur = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            torch.distributed.all_reduce(self.model._gbuf[:self._vd], group=self.pg)
+        self._b1_done = torch.cuda.Event()
+        self._b1_done.record(self._side)
 
     def exchange_desc(self) -> str:
         if not self.dp:
             return "none (single GPU)"
-        how = "one graph per step incl. the collective" if (self.use_graph and self.dp_graph == "one") else \
-            ("grad graph + eager collective + Adam graph" if self.use_graph else "eager")
-        return f"one RCCL all-reduce of the flat gradient arena after the backward; {how}"
+        how = "one graph per step incl. the exchange" if (self.use_graph and self.dp_graph == "one") else \
+            ("grad graph + eager exchange + Adam graph" if self.use_graph else "eager")
+        what = {"rccl": "one RCCL all-reduce of the flat gradient arena after the backward",
+                "rccl_bucketed": "two RCCL all-reduces: the dense item-table gradient on a side stream under the encoder backward, "
+                                 "the encoder gradients + lookup rows after it",
+                "p2p": "one cross-GPU barrier kernel, then the fused Adam reads every rank's IPC-mapped gradient arena over xGMI "
+                       "(no collective library in the data path)"}[self.exchange]
+        return f"{what}; {how}"
 
     def exchange_report(self) -> dict:
-        return {"kind": "rccl", "buckets": 1, "bytes": int(self.model._garena.numel() * 4), "launch": self.dp_graph}
+        m = self.model
+        n = int(m._numel * 4)
+        if self.exchange == "rccl_bucketed":
+            vd = int(self._vd * 4)
+            return {"kind": "rccl_bucketed", "buckets": 2, "overlapped_bytes": vd, "exposed_bytes": n, "launch": self.dp_graph}
+        if self.exchange == "p2p":
+            return {"kind": "p2p", "buckets": 0, "remote_read_bytes": n * (self.world - 1), "exposed": "1 barrier kernel + remote reads inside Adam",
+                    "timed_out": self._px.timed_out(), "launch": self.dp_graph}
+        return {"kind": "rccl", "buckets": 1, "exposed_bytes": n, "launch": self.dp_graph}
 
     def _sync_replicas(self):
         """Data parallel: only gradients are exchanged, so the replicas must START identical -- rank 0's parameters,
@@ -131,8 +183,13 @@ class Trainer:
         plan = m._run_forward(ids, train=True, new_step=True)
         m._run_loss(plan, ans)
         m._run_backward(plan)
-        scale = allreduce_sum_(m._garena, self.pg, force=True)
-        m.adam_step(grad_scale=scale)
+        if self.exchange == "p2p":                  # (parity 0 arena; not the indexed fast path)
+            self._px.barrier(torch.cuda.current_stream(self.device).cuda_stream)
+            m.adam_step(grad_scale=1.0 / self.world, grad_srcs=self._px.grad_srcs(0))
+            self._px.barrier(torch.cuda.current_stream(self.device).cuda_stream)       # single arena here: readers done
+        else:
+            scale = allreduce_sum_(m._gbuf if self.exchange == "rccl_bucketed" else m._garena, self.pg, force=True)
+            m.adam_step(grad_scale=scale)
         from . import _lib as L
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
@@ -166,52 +223,77 @@ class Trainer:
         (``dp_graph="one"``, default), or as graph A + eager all-reduce + graph B (``"two"``; also the fallback when the
         capture of the collective is refused).  Env BSAREC_DP_GRAPH selects."""
         m, B = self.model, dl.batch_size
-        key = ("indexed", B, pbuf.data_ptr(), pbuf.shape[0], cursor.data_ptr(), None if loss_sum is None else loss_sum.data_ptr())
+        p2p, bucketed = self.exchange == "p2p", self.exchange == "rccl_bucketed"
+        parity = (self._nsteps & 1) if p2p else 0
+        self._nsteps += 1
+        key = ("indexed", B, pbuf.data_ptr(), pbuf.shape[0], cursor.data_ptr(), None if loss_sum is None else loss_sum.data_ptr(), parity)
+        st = lambda: torch.cuda.current_stream(self.device).cuda_stream
 
         def grad_part():
             if not self.dp:
                 loss = m.train_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B)
             else:
-                loss = m.grad_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B, tick_adam=True)
+                loss = m.grad_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B, tick_adam=True, parity=parity)
             if loss_sum is not None:
                 loss_sum.add_(loss)
             return loss
 
+        def exchange(hooked):
+            if p2p:
+                self._px.barrier(st())                  # every rank's backward is complete and visible
+            elif bucketed:
+                if not hooked:                          # the dense bucket was not started under the backward
+                    torch.distributed.all_reduce(m._gbuf[:self._vd], group=self.pg)
+                torch.distributed.all_reduce(m._gbuf[self._vd:], group=self.pg)     # encoder gradients + lookup rows
+                if hooked:
+                    torch.cuda.current_stream(self.device).wait_event(self._b1_done)
+            else:
+                allreduce_sum_(m._garena, self.pg, force=True)
+
         def adam_part():
-            m.adam_step(grad_scale=1.0 / self.world, tick=False)      # t / bias corrections: advanced by the grad step
+            # t / bias corrections: advanced by the grad step
+            m.adam_step(grad_scale=1.0 / self.world, tick=False, grad_srcs=self._px.grad_srcs(parity) if p2p else None)
 
-        def exchange():
-            allreduce_sum_(m._garena, self.pg, force=True)
+        def set_hook(on):
+            if bucketed:
+                m.set_dense_grad_hook(self._dense_hook if on else None)
 
+        capturable = p2p or self._backend == "nccl" if self.dp else True
         if not self.use_graph:
+            set_hook(True)
             loss = grad_part()
             if self.dp:
-                exchange()
+                exchange(bucketed)
                 adam_part()
             return loss
         g = self._graphs.get(key)
         if g is None:
-            m._plan(B)
+            m._plan(B, parity)
+            set_hook(False)
             loss = grad_part()                                # eager first step: static buffers, kernel attributes,
             if self.dp:                                       # RCCL communicator and its buffers
-                exchange()
+                exchange(False)
                 adam_part()
             torch.cuda.synchronize()
             ga = gb = None
-            if self.dp and self.dp_graph == "one":
-                # the whole data-parallel step as ONE graph: RCCL's all-reduce kernel is captured between the
-                # gradient kernels and Adam, so a step costs one graph launch and no host round trip
+            if self.dp and self.dp_graph == "one" and capturable:
+                # the whole data-parallel step as ONE graph: the exchange (RCCL kernels, incl. the side-stream bucket, or the
+                # barrier kernel) is captured between the gradient kernels and Adam: one graph launch, no host round trip
                 try:
+                    set_hook(True)
                     ga = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(ga):
                         gloss = grad_part()
-                        exchange()
+                        exchange(bucketed)
                         adam_part()
                 except Exception as e:                        # capture of the collective refused: two graphs instead
                     self.logger.info(f"one-graph data-parallel capture failed ({type(e).__name__}: {e}); using two graphs")
                     self.dp_graph, ga = "two", None
                     torch.cuda.synchronize()
+            elif self.dp:
+                self.dp_graph = "two"
             if ga is None:
+                set_hook(False)
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
                     gloss = grad_part()
@@ -222,10 +304,10 @@ class Trainer:
             self._graphs[key] = (ga, gb, gloss)
             return loss
         ga, gb, gloss = g
-        m._fresh_step_counter(m._plan(B))                     # a begin-style step (eager tail batch) came before: new masks
+        m._fresh_step_counter(m._plan(B, parity))             # a begin-style step (eager tail batch) came before: new masks
         ga.replay()
         if gb is not None:
-            exchange()
+            exchange(False)
             gb.replay()
         return gloss
 

@@ -126,6 +126,16 @@ int bsarec_shadow_refresh(bsarec_plan_t *plan, void *stream);
 int bsarec_buffer_is_bf16(const bsarec_plan_t *plan, int buffer, int layer);
 void bsarec_plan_destroy(bsarec_plan_t *plan);
 
+/* Data-parallel bucketing: the dense part of the item-table gradient, dE = dlogits^T . h_last, is complete
+ * right after the logits backward -- long before the rest of the gradient.  `hook` (may be null) is called by
+ * bsarec_backward / bsarec_*_step_indexed on the calling thread as soon as that kernel is ENQUEUED on `stream`, so that
+ * the host can start exchanging grads->item_emb on a side stream under the whole encoder backward (record an event on
+ * `stream`, let the side stream wait for it).  `lookup_grad` (may be null): [V, d] buffer that then receives the
+ * lookup-path rows (the embedding scatter at the END of the backward) instead of grads->item_emb, so that the early
+ * exchange is not disturbed; hand it to the update as bsarec_adam_t.grads2. */
+typedef void (*bsarec_hook_t)(void *user, void *stream);
+int bsarec_plan_set_dense_grad_hook(bsarec_plan_t *plan, bsarec_hook_t hook, void *user, float *lookup_grad);
+
 /* Byte offset of a named buffer inside the workspace, or -1. */
 long bsarec_buffer_offset(const bsarec_plan_t *plan, int buffer, int layer);
 
@@ -175,6 +185,12 @@ typedef struct {
     float grad_scale;         /* g is scaled by this first (1/world_size after a summing all-reduce; else 1) */
     void *shadow_bf16;        /* null, or bf16[n] mirror of params (cfg.storage = 1): the update also writes the rounded */
     long shadow_from;         /*   parameter to shadow_bf16[i] for i >= shadow_from (the tensors after the item table) */
+    /* ---- data-parallel gradient sources (all optional; zero-filled = g is `grads`) ---- */
+    float *grads2;            /* a second arena ADDED to the first grads2_n elements of g and zeroed by the update: the   */
+    long grads2_n;            /*   lookup-path rows of the item table when its dense part was exchanged early (buckets)    */
+    int n_grad_srcs;          /* > 0: g = sum of grad_srcs[0 .. n) in index order (`grads` ignored) -- the one-shot       */
+    const float *grad_srcs[8];/*   peer-to-peer exchange of bsarec_comm.h: every rank's arena in RANK order, so that every */
+                              /*   replica forms the identical sum                                                        */
 } bsarec_adam_t;
 
 /* Advance Adam's t / bias corrections in `state`, then update. */

@@ -1,7 +1,12 @@
-"""Two data-parallel ranks on ONE GPU (gloo backend for the exchange, so that no second device is needed): the
-sharded step -- same permutation on both ranks, rank slice of every global batch, summing all-reduce of the flat
-gradient arena, Adam on sum / world -- must leave both replicas identical and equal to a single process that trains on
-the global batch of 2B (dropout off: the Philox streams are rank-decorrelated by design)."""
+"""Two data-parallel ranks on ONE GPU (gloo for the control plane, so that no second device is needed): the sharded
+step -- same permutation on both ranks, rank slice of every global batch, ONE gradient exchange, Adam on sum / world --
+must leave both replicas bit-identical and equal to a single process that trains on the global batch of 2B (dropout
+off: the Philox streams are rank-decorrelated by design).  Every form of the exchange (bsarec_amd/dp.py):
+  rccl           one all-reduce of the flat arena (gloo stands in for RCCL here),
+  rccl_bucketed  dense item-table bucket started by the library's hook right after the logits backward + second bucket
+                 (encoder gradients + lookup rows) after the backward,
+  p2p            IPC-mapped peer arenas, one barrier kernel, the fused Adam reads both ranks' arenas -- the real data
+                 path (hipIpc mappings, flags, step-parity arenas), with both ranks on the one GPU of the box."""
 import argparse
 import os
 import socket
@@ -27,7 +32,7 @@ def _table():
     return u[:1024], x[:1024], a_[:1024]
 
 
-def _worker(rank, world, port, graph, out_dir):
+def _worker(rank, world, port, graph, exchange, out_dir):
     import torch.distributed as dist
     from bsarec_amd import BSARecModel, data as D
     from bsarec_amd.trainer import Trainer
@@ -39,22 +44,28 @@ def _worker(rank, world, port, graph, out_dir):
         model = BSARecModel(_ns()).cuda()
         model.set_seed(5, rank)
         dl = D.DeviceBatches(u, x, a_, 64, "cuda", shuffle=True, seed=11, rank=rank, world=world)
-        tr = Trainer(model, dl, None, None, _ns(), None, use_graph=graph, process_group=dist.group.WORLD)
-        tr.dp_graph = "two"                      # gloo's all-reduce cannot be captured: grad graph + eager exchange + Adam graph
+        tr = Trainer(model, dl, None, None, _ns(), None, use_graph=graph, process_group=dist.group.WORLD, exchange=exchange)
+        assert tr.exchange == exchange, (tr.exchange, exchange)       # no silent fallback in this test
+        if exchange != "p2p":
+            tr.dp_graph = "two"                  # gloo's all-reduce cannot be captured: grad graph + eager exchange + Adam graph
         losses = [float(tr.train(e)["rec_loss"]) for e in range(2)]
+        if exchange == "p2p":
+            assert not tr._px.timed_out()
+            assert tr.dp_graph == "one" or not graph
         sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.asarray(losses), **sd)
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "rccl_bucketed", "p2p"])
 @pytest.mark.parametrize("graph", [False, True])
-def test_two_ranks_equal_each_other_and_the_global_batch(graph, tmp_path):
+def test_two_ranks_equal_each_other_and_the_global_batch(graph, exchange, tmp_path):
     import torch.multiprocessing as mp
     from bsarec_amd import BSARecModel, data as D
     from bsarec_amd.trainer import Trainer
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, graph, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, graph, exchange, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in r0.files:
         np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)          # replicas stay bit-identical

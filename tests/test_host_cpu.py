@@ -35,6 +35,17 @@ def test_library_exports_every_header_symbol():
     assert lib.bsarec_abi_version() == _lib.ABI_VERSION
 
 
+def test_library_exports_every_comm_header_symbol():
+    """include/bsarec_comm.h (peer-to-peer gradient exchange): every declared entry point is exported and bound."""
+    from bsarec_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "bsarec_comm.h")).read()
+    declared = set(re.findall(r"\b(bsarec_comm_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.COMM_EXPORTS), declared ^ set(_lib.COMM_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
 def test_workspace_query_and_shape_limits():
     import ctypes as C
     from bsarec_amd import _lib
@@ -180,6 +191,7 @@ def test_header_is_plain_c_and_links_from_c_and_cpp(tmp_path):
         pytest.skip("library or gcc missing")
     src = r"""
 #include "bsarec_hip.h"
+#include "bsarec_comm.h"
 #include <stdio.h>
 int main(void) {
     bsarec_config_t cfg = {256, 50, 64, 2, 2, 3417, 2, 0.9f, 1e-12f, 0.5f, 0.5f, 0};
