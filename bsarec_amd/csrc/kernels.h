@@ -667,9 +667,13 @@ __device__ __forceinline__ unsigned adam_pk_bf16(float a, float b) {
 // can serve a line from the previous step.
 struct GradSrcs { int nsrc; const float* src[8]; float* g2; long n2_4; };
 __device__ __forceinline__ f32x4 ld4_sys(const float* p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
+    // two 8-byte relaxed system-scope atomic loads (global_load_dwordx2 ... sc0 sc1): loads the compiler itself tracks
+    // (an inline-asm load would need a hand-placed s_waitcnt that the scheduler is free to move the uses across)
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+    const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return f32x4{__builtin_bit_cast(float, (uint32_t)a), __builtin_bit_cast(float, (uint32_t)(a >> 32)),
+                 __builtin_bit_cast(float, (uint32_t)b), __builtin_bit_cast(float, (uint32_t)(b >> 32))};
 }
 __global__ void __launch_bounds__(ROW_THREADS)
 adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n4,
@@ -683,7 +687,6 @@ adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restric
             f32x4 part[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) if (r < S.nsrc) part[r] = ld4_sys(S.src[r] + 4 * i);     // all peers in flight
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             gi = part[0];
 #pragma unroll
             for (int r = 1; r < 8; ++r) if (r < S.nsrc) gi += part[r];                            // rank order on every rank
