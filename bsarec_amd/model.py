@@ -67,7 +67,7 @@ def _twiddle(Lq: int) -> torch.Tensor:
 class _Plan:
     """One launch plan (fixed batch size) + the workspace tensor it carves."""
 
-    def __init__(self, model: "BSARecModel", batch: int, garena=None, share_ws_with: "Optional[_Plan]" = None):
+    def __init__(self, model: "BSARecModel", batch: int, garena=None):
         lib = L.load()
         a = model.args
         self.cfg = L.Config(batch, a.max_seq_length, a.hidden_size, a.num_attention_heads, a.num_hidden_layers,
@@ -85,14 +85,10 @@ class _Plan:
                              "L <= 256, hidden <= 256 and % 4 == 0, head size % 4 == 0, cutoff_bins*hidden <= 8192; "
                              "storage = bf16 needs the fused shape hidden = 64, L <= 64)")
         dev = model._arena.device
-        if share_ws_with is not None:                   # a second plan over the same workspace (never run concurrently):
-            self.ws = share_ws_with.ws                  # the other gradient arena of the peer-to-peer exchange
-            assert self.ws.numel() >= nbytes
-        else:
-            self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-            off = (-self.ws.data_ptr()) % 256
-            self.ws = self.ws[off:off + nbytes]
-            self.ws.zero_()
+        self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        off = (-self.ws.data_ptr()) % 256
+        self.ws = self.ws[off:off + nbytes]
+        self.ws.zero_()
         self.batch = batch
         self.handle = C.c_void_p()
         self.bf16 = bool(self.cfg.storage)
@@ -337,8 +333,8 @@ class BSARecModel(nn.Module):
                 self.set_seed(self._seed)
             if parity == 0:
                 self._plans[key] = _Plan(self, batch)
-            else:                                          # same workspace, the other gradient arena
-                self._plans[key] = _Plan(self, batch, garena=self._garena_alt, share_ws_with=self._plan(batch, 0))
+            else:       # the other gradient arena; its own workspace (the reduction job table inside it names the arena)
+                self._plans[key] = _Plan(self, batch, garena=self._garena_alt)
             if self._lookup is not None or self._dense_hook is not None:
                 self._install_hook(self._plans[key])
         return self._plans[key]
