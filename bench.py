@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra C3-shape / bf16 measurements of the N = 1 line")
     ap.add_argument("--dp", action="store_true", help="take the data-parallel step (RCCL all-reduce) even with one rank")
-    ap.add_argument("--exchange", choices=["auto", "rccl", "p2p"], default="auto",
+    ap.add_argument("--exchange", choices=["auto", "rccl", "rccl_bucketed", "p2p"], default="auto",
                     help="gradient exchange of the data-parallel step: RCCL all-reduce(s), or the one-shot peer-to-peer read-reduce "
                          "fused into Adam (IPC-mapped peer arenas over xGMI)")
     a = ap.parse_args()
@@ -161,8 +161,8 @@ def main():
     # exchange then goes through the host, so the step uses grad graph + eager all-reduce + Adam graph
     backend = os.environ.get("BSAREC_DIST_BACKEND", "nccl")
     if backend != "nccl":
-        local = 0
-        os.environ.setdefault("BSAREC_DP_GRAPH", "two")
+        local = 0                 # (the Trainer itself falls back to grad graph + eager exchange + Adam graph where the
+                                  #  exchange cannot be captured, i.e. for gloo collectives)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
@@ -292,6 +292,13 @@ def main():
         out["allreduce_us"] = round(ev0.elapsed_time(ev1) * 1e3 / 50, 2)
         out["allreduce_bytes"] = int(g.numel() * 4)
         out["exchange"] = trainer.exchange_report()
+        # the replicas must still be bit-identical after the timed steps (only gradients are exchanged)
+        cs = model._arena.double().sum().view(1)
+        lo, hi = cs.clone(), cs.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=pg)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=pg)
+        out["replicas_identical"] = bool(lo.item() == hi.item())
+        assert out["replicas_identical"], "data-parallel replicas diverged"
 
     flops_seq = train_flops_per_seq(a)
     peak = FP32_MFMA_PEAK_TFLOPS if a.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS

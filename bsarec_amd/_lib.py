@@ -151,7 +151,7 @@ EXPORTS = {
 
 # include/bsarec_comm.h
 COMM_EXPORTS = {
-    "bsarec_comm_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "bsarec_comm_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]),
     "bsarec_comm_free": (C.c_int, [C.c_void_p]),
     "bsarec_comm_export": (C.c_int, [C.c_void_p, C.c_char_p]),
     "bsarec_comm_import": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

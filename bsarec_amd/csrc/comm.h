@@ -34,9 +34,9 @@ comm_barrier_kernel(const bsarec_comm_t C) {
     __threadfence_system();
 }
 
-extern "C" int bsarec_comm_alloc(void** dev_ptr, size_t bytes) {
+extern "C" int bsarec_comm_alloc(void** dev_ptr, size_t bytes, int uncached) {
     if (!dev_ptr || bytes == 0) return -10;
-    hipError_t e = hipMalloc(dev_ptr, bytes);
+    hipError_t e = uncached ? hipExtMallocWithFlags(dev_ptr, bytes, hipDeviceMallocUncached) : hipMalloc(dev_ptr, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipMemset(*dev_ptr, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();

@@ -56,7 +56,8 @@ def _as_tensor(ptr: int, numel: int, dtype: torch.dtype, device) -> torch.Tensor
 
 class PeerExchange:
     """The ``p2p`` exchange: two gradient arenas (step parity) + barrier flags of every rank, IPC-mapped into this
-    process.  Allocation layout per rank (one hipMalloc): [arena 0 | arena 1 | flags u64[8] | epoch u64 | error u32]."""
+    process.  Two allocations per rank: [arena 0 | arena 1] (hipMalloc) and [flags u64[8] | epoch u64 | error u32]
+    (uncached, fine-grained: peers write the flags, this GPU polls them)."""
 
     @classmethod
     def create(cls, numel: int, group, device, logger=None, timeout_ms: int = 5000):
@@ -85,37 +86,40 @@ class PeerExchange:
         self.world = torch.distributed.get_world_size(group)
         self.numel = numel
         self.arena_bytes = (numel * 4 + 255) // 256 * 256
-        self.nbytes = 2 * self.arena_bytes + 256
-        self.ok, self.base, raw = self.world <= 8, None, None     # one xGMI node
+        self.ok, self.base, self.fbase, raw = self.world <= 8, None, None, None     # one xGMI node
         if self.ok:
-            base, handle = C.c_void_p(), C.create_string_buffer(64)
-            self.ok = lib.bsarec_comm_alloc(C.byref(base), self.nbytes) == 0
+            base, fbase = C.c_void_p(), C.c_void_p()
+            h1, h2 = C.create_string_buffer(64), C.create_string_buffer(64)
+            self.ok = lib.bsarec_comm_alloc(C.byref(base), 2 * self.arena_bytes, 0) == 0 and \
+                lib.bsarec_comm_alloc(C.byref(fbase), 256, 1) == 0
             if self.ok:
-                self.base = base.value
-                self.ok = lib.bsarec_comm_export(self.base, handle) == 0
-                raw = bytes(handle.raw)
+                self.base, self.fbase = base.value, fbase.value
+                self.ok = lib.bsarec_comm_export(self.base, h1) == 0 and lib.bsarec_comm_export(self.fbase, h2) == 0
+                raw = (bytes(h1.raw), bytes(h2.raw))
         handles = [None] * self.world
         torch.distributed.all_gather_object(handles, raw if self.ok else None, group=group)     # reached by every rank
-        self.peer_base = []
+        self.peer_base, self.peer_flags = [], []
         self.ok = self.ok and all(h is not None for h in handles)
         for r in range(self.world):
             if r == self.rank or not self.ok:
                 self.peer_base.append(self.base)
+                self.peer_flags.append(self.fbase)
             else:
-                p = C.c_void_p()
-                if lib.bsarec_comm_import(handles[r], C.byref(p)) != 0:
+                p, q = C.c_void_p(), C.c_void_p()
+                if lib.bsarec_comm_import(handles[r][0], C.byref(p)) != 0 or lib.bsarec_comm_import(handles[r][1], C.byref(q)) != 0:
                     self.ok = False
                 self.peer_base.append(p.value)
+                self.peer_flags.append(q.value)
         if not self.ok:
             return
         self.comm = L.Comm()
         self.comm.rank, self.comm.world, self.comm.timeout_ms = self.rank, self.world, int(timeout_ms)
         for r in range(self.world):
-            self.comm.flags[r] = self.peer_base[r] + 2 * self.arena_bytes
-        self.comm.epoch = self.base + 2 * self.arena_bytes + 64
-        self.comm.error = self.base + 2 * self.arena_bytes + 72
+            self.comm.flags[r] = self.peer_flags[r]
+        self.comm.epoch = self.fbase + 64
+        self.comm.error = self.fbase + 72
         self.arenas = [_as_tensor(self.base + q * self.arena_bytes, numel, torch.float32, device) for q in range(2)]
-        self._err = _as_tensor(self.base + 2 * self.arena_bytes + 72, 1, torch.int32, device)
+        self._err = _as_tensor(self.fbase + 72, 1, torch.int32, device)
         # (create() follows with a collective that every rank reaches: nobody uses a mapping before all ranks have theirs)
 
     def grad_srcs(self, parity: int):
@@ -150,10 +154,12 @@ class PeerExchange:
             return
         try:
             torch.cuda.synchronize(self.device)
-            for r, p in enumerate(self.peer_base):
+            for r in range(self.world):
                 if r != self.rank:
-                    self.lib.bsarec_comm_release(p)
+                    self.lib.bsarec_comm_release(self.peer_base[r])
+                    self.lib.bsarec_comm_release(self.peer_flags[r])
             self.lib.bsarec_comm_free(self.base)
+            self.lib.bsarec_comm_free(self.fbase)
         finally:
             self.base = None
 

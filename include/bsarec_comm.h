@@ -22,8 +22,11 @@ extern "C" {
 #define BSAREC_MAX_PEERS 8
 #define BSAREC_IPC_HANDLE_BYTES 64
 
-/* hipMalloc + zero fill / hipFree: memory that can be exported to the other ranks of the node. */
-int bsarec_comm_alloc(void **dev_ptr, size_t bytes);
+/* Device memory that can be exported to the other ranks of the node, zero-filled.  uncached = 0: hipMalloc (gradient
+ * arenas: bulk data, made visible by kernel boundaries + the barrier's system-scope fences); uncached = 1:
+ * hipExtMallocWithFlags(hipDeviceMallocUncached), fine-grained memory for the barrier flags that peers write and this
+ * GPU polls.  bsarec_comm_free releases either. */
+int bsarec_comm_alloc(void **dev_ptr, size_t bytes, int uncached);
 int bsarec_comm_free(void *dev_ptr);
 /* hipIpcGetMemHandle / hipIpcOpenMemHandle(lazy peer access) / hipIpcCloseMemHandle.  Handles are 64 opaque bytes the
  * host exchanges out of band (torch.distributed all_gather_object in the shipped host code). */
