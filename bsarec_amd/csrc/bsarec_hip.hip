@@ -141,8 +141,10 @@ struct bsarec_plan {
     float* part_cwL[BSAREC_MAX_LAYERS];        // FMLPRec: per-sequence d(complex_weight) [B][cb][d][2]
     float *top_dq, *top_dO, *top_dT, *top_dU, *top_ak, *top_rk, *top_av, *top_rv;              // [2][B][d] key / value bias partials of the pruned top block; [nsplit][4d] sink
     int* blockmap; int red_blocks;           // flat block -> (job, chunk) table of the final gradient reduction
+    long red_elems; const float *red_lo, *red_hi;   // what the reduction jobs write: element count, address range
     // options resolved from cfg (0 = default there)
     int top_slabs; bool embed_in_block, direct_dw;
+    bool scatter_in_block;                     // fused path: the embedding-gradient scatter rides in the bottom block's backward
     ProfState prof;
     long long* stamps = nullptr;             // diagnostic stamp buffer (bsarec_debug_stamps)
     bsarec_hook_t dense_hook = nullptr; void* dense_hook_user = nullptr;   // bsarec_plan_set_dense_grad_hook
@@ -204,6 +206,7 @@ static void derive(bsarec_plan& p) {
     const int want_splits = c.splits > 0 ? c.splits : 40;
     p.top_slabs = c.top_slabs > 0 ? c.top_slabs : 2;
     p.embed_in_block = !c.separate_embed || p.bf;     // bf16 storage: X[0] is written by the block kernel only
+    p.scatter_in_block = p.fused && !c.separate_embed;
     p.direct_dw = !c.dw_tiled && (long)p.T * 4 * c.hidden * 4 < (1L << 31);      // its operands sit behind 32-bit buffer offsets
     long ch = rup(cdiv(p.T, want_splits), GEMM_BK);
     if (ch < 64) ch = 64;
@@ -342,7 +345,11 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     }
     add(p->part_ln0 + 0L * nb * d, p->G.ln_w, nb, d);
     add(p->part_ln0 + 1L * nb * d, p->G.ln_b, nb, d);
-    add(p->part_pos, p->G.pos_emb, p->pos_slices, (long)cfg->seq_len * d);
+    if (p->scatter_in_block) {   // the position gradient = sum over the batch of the embedding gradient rows the block kernel wrote
+        ReduceJob j; j.src = p->dz; j.dst = p->G.pos_emb; j.nsplit = cfg->batch; j.len = (int)((long)cfg->seq_len * d);
+        j.stride = (long)cfg->seq_len * d; j.scale = 1.f; j.pad = 0;
+        jobs.push_back(j);
+    } else add(p->part_pos, p->G.pos_emb, p->pos_slices, (long)cfg->seq_len * d);
     if (cfg->filter_kind == 1)                 // FMLPRec: d(complex_weight) of every layer, summed over the sequences
         for (int l = 0; l < cfg->layers; ++l)
             add(p->part_cwL[l], p->G.layer[l].filter_cw, cfg->batch, (long)cfg->cutoff_bins * d * 2);
@@ -362,6 +369,12 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
     for (size_t j = 0; j < jobs.size(); ++j)
         for (int ch = 0; ch < cdiv(jobs[j].len, 64); ++ch) bmap.push_back((int)(j << 16) | ch);
     p->red_blocks = (int)bmap.size();
+    p->red_elems = 0; p->red_lo = nullptr; p->red_hi = nullptr;
+    for (const ReduceJob& j : jobs) {
+        p->red_elems += j.len;
+        if (!p->red_lo || j.dst < p->red_lo) p->red_lo = j.dst;
+        if (!p->red_hi || j.dst + j.len > p->red_hi) p->red_hi = j.dst + j.len;
+    }
     hipError_t e = hipMemcpyAsync(p->jobs, jobs.data(), jobs.size() * sizeof(ReduceJob), hipMemcpyHostToDevice,
                                   (hipStream_t)stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p->blockmap, bmap.data(), bmap.size() * sizeof(int), hipMemcpyHostToDevice,
@@ -564,6 +577,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     if (l == 0) {       // the embedding front-end's backward (Drop + LayerNorm) rides in the bottom block's epilogue
         F.e_dz = p.dz; F.e_xhat = p.xhat0; F.e_rstd = p.rstd0; F.e_g = p.P.ln_w;
         F.e_pg = p.part_ln0; F.e_pb = p.part_ln0 + nb * d; F.e_drop = make_drop(p, c.p_hidden, 0, tr);
+        if (p.scatter_in_block) { F.e_dE = p.lookup_grad ? p.lookup_grad : p.G.item_emb; F.e_ids32 = p.ids32; }
     }
     F.dT = p.dT; F.dU = p.dU; F.dO = p.dO; F.dq = p.dq; F.dk = p.dk; F.dv = p.dv;
     F.pg_ff = p.part_ln + 0 * nb * d; F.pb_ff = p.part_ln + 1 * nb * d; F.pg_a = p.part_ln + 2 * nb * d;
@@ -838,7 +852,7 @@ static int loss_pair(bsarec_plan_t* p, const int64_t* pos_ids, const int64_t* ne
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick);
+static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, const bsarec_adam_t* fuse_adam = nullptr);
 
 extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
     TickP none;
@@ -846,7 +860,20 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
     return backward_impl(p, stream, none);
 }
 
-static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
+// Can the final gradient reduction and Adam be one launch (reduce_adam_kernel)?  Needs the direct weight-gradient
+// launch of block 0 to host the step tick, plain single-GPU gradient sources, and every gradient tensor inside the flat
+// arena the update walks (item table + the reduction jobs' targets = the whole arena).
+static bool can_fuse_adam(const bsarec_plan& p, const bsarec_adam_t& a) {
+    if (!p.fused || !p.direct_dw || p.loss_kind != 0) return false;
+    if (a.grads2 || a.n_grad_srcs > 0 || a.grad_scale != 1.0f) return false;
+    if (!p.G.item_emb || p.G.item_emb < a.grads) return false;
+    const long item = (long)p.cfg.item_size * p.cfg.hidden;
+    const long off = p.G.item_emb - a.grads;
+    if (off < 0 || off + item > a.n || (off & 3) || (item & 3)) return false;
+    return p.red_elems + item == a.n && p.red_lo >= a.grads && p.red_hi <= a.grads + a.n;
+}
+
+static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, const bsarec_adam_t* fuse_adam) {
     if (!p) return -10;
     if (!p->G.item_emb) return -13;
     PlanScope scope(p);
@@ -1080,8 +1107,12 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
                 if (top_pruned) { DW.nsmall = dw_nu; DW.small_slabs = std::min(p->top_slabs, ns); }
                 else {
                     DW.nunits = dw_nu; DW.nslab = ns;
+                    TickP tk_here;                     // the step tick rides in block 0's launch when Adam is fused into the reduction
+                    memset(&tk_here, 0, sizeof(tk_here));
+                    if (fuse_adam && l == 0) tk_here = tick;
                     ProfScope prof(BSAREC_K_DW1, s);
-                    LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * (dw_nu - DW.nsmall) + DW.nsmall * DW.small_slabs), dim3(256), 0, s, DW);
+                    LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * (dw_nu - DW.nsmall) + DW.nsmall * DW.small_slabs + (tk_here.state ? 1 : 0)),
+                           dim3(256), 0, s, DW, tk_here);
                     HIPCHK(hipGetLastError());
                     dw_np = 0; dw_nu = 0; DW.nsmall = 0; DW.small_slabs = 0;
                 }
@@ -1110,6 +1141,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
             DISPATCH_LPR(d, LAUNCH((ln_bwd_kernel<LPR, 2>), dim3(nb), dim3(ROW_THREADS), 0, se, dY, a, a, p->dz, T, d, p->rows_pb));
             HIPCHK(hipGetLastError());
         }
+        if (!p->scatter_in_block)
         DISPATCH_LPR(d, {
             constexpr int CHUNK = SCATTER_FLOATS / (LPR * 4);
             constexpr size_t smem = SCATTER_FLOATS * 4 + 2 * CHUNK * 4;
@@ -1126,6 +1158,19 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick) {
         });
         // ---- ONE deterministic second-stage reduction for every split-K slab and LayerNorm / beta partial
         // (no empty blocks: flat block map); its extra last block closes the optimisation step when asked to
+        if (fuse_adam) {
+            const bsarec_adam_t& a = *fuse_adam;
+            AdamFuseP A;
+            memset(&A, 0, sizeof(A));
+            A.w = a.params; A.g = const_cast<float*>(a.grads); A.m = a.exp_avg; A.v = a.exp_avg_sq;
+            A.b1 = a.beta1; A.b2 = a.beta2; A.eps = a.eps; A.wd = a.weight_decay;
+            A.shadow = (unsigned short*)a.shadow_bf16; A.shadow_from = a.shadow_bf16 ? a.shadow_from : a.n;
+            A.item_off = p->G.item_emb - a.grads; A.item_n4 = (long)c.item_size * d / 4;
+            int ab = cdiv(A.item_n4, ROW_THREADS);
+            if (ab > 1024) ab = 1024;
+            LAUNCH(reduce_adam_kernel, dim3(p->red_blocks + ab), dim3(ROW_THREADS), 0, s, p->pruned ? p->jobs_pruned : p->jobs,
+                   p->blockmap, p->red_blocks, (const uint64_t*)p->state, A);
+        } else
         LAUNCH(multi_reduce_flat_kernel, dim3(p->red_blocks + (tick.state ? 1 : 0)), dim3(ROW_THREADS), 0, s,
                p->pruned ? p->jobs_pruned : p->jobs, p->blockmap, p->red_blocks, tick);
         HIPCHK(hipGetLastError());
@@ -1205,8 +1250,10 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
     RET(loss_impl(p, answers_buf, stream, false));
     // the extra block of the final gradient reduction closes the step: mean loss, Adam t and bias corrections, next
     // forward-step index, cursor += B
-    RET(backward_impl(p, stream, make_tick(p->state, 1, a->lr, a->beta1, a->beta2, p->loss_rows, p->cfg.batch, p->loss, cursor,
-                                           p->cfg.batch, 1)));
+    const TickP tk = make_tick(p->state, 1, a->lr, a->beta1, a->beta2, p->loss_rows, p->cfg.batch, p->loss, cursor, p->cfg.batch, 1);
+    if (can_fuse_adam(*p, *a) && !p->cfg.separate_embed)       // 9 launches: the last one reduces and updates
+        return backward_impl(p, stream, tk, a);
+    RET(backward_impl(p, stream, tk));
     return adam_launch(*a, p->state, s);
 }
 

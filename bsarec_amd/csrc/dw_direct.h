@@ -203,9 +203,13 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
 
 
 // The host builds the unit table (64 x 64 tiles of the six problems: 4 + 4 + 4 = 12 units at hidden = 64).
+// tk.state != null: one extra (last) workgroup closes the optimisation step here -- mean loss, Adam's t and bias
+// corrections, next dropout step, batch cursor (kernels.h, tick_body) -- so that the step's final kernel can reduce AND
+// update with a read-only state.  Every reader of the dropout step / cursor of this step has run before this launch.
 __global__ void __launch_bounds__(256)
-dw_direct_kernel(const DwP G) {
+dw_direct_kernel(const DwP G, const TickP tk) {
     __shared__ __attribute__((aligned(16))) float red[3][66][64];      // accumulators (64) + bias sums (2) of waves 1..3
+    if (tk.state && blockIdx.x == gridDim.x - 1) { tick_body(tk, &red[0][0][0]); return; }
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All units of
     // one slab slice read the same token rows (X feeds the q/k/v tiles, hmix and dT2 four tiles each), so a slice is
     // kept on ONE XCD and the re-reads hit that L2.

@@ -707,6 +707,74 @@ adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restric
     }
 }
 
+// The single-GPU step's last kernel: the final gradient reduction and Adam in ONE launch.  Blocks [0, nblocks) sum one
+// 64-element chunk of a reduction job (all split-K slabs / LayerNorm / beta / position partials), store the gradient
+// and update those 64 parameters on the spot; the remaining blocks update the one tensor no job produces -- the item
+// table, whose gradient (dense logits part + lookup scatter) was finished by earlier kernels.  Adam's t / bias
+// corrections were advanced by the step tick in the PREVIOUS kernel (dw_direct_kernel's extra block), so `state` is
+// read-only here.  Same arithmetic, element for element, as adam_kernel.
+struct AdamFuseP {
+    float *w, *g, *m, *v; float b1, b2, eps, wd;
+    unsigned short* shadow; long shadow_from;
+    long item_off, item_n4;            // the item table inside the flat arena: element offset, float4 count
+};
+__global__ void __launch_bounds__(ROW_THREADS)
+reduce_adam_kernel(const ReduceJob* __restrict__ jobs, const int* __restrict__ blockmap, int nblocks,
+                   const uint64_t* __restrict__ state, const AdamFuseP A) {
+    __shared__ float red[ROW_THREADS];
+    const float* f = reinterpret_cast<const float*>(state + 3);
+    const float step_size = f[0], bc2s = f[1];
+    if ((int)blockIdx.x < nblocks) {
+        const int bm = blockmap[blockIdx.x];
+        const ReduceJob j = jobs[bm >> 16];
+        float (*r4)[64] = reinterpret_cast<float(*)[64]>(red);
+        const int e = threadIdx.x & 63, sg = threadIdx.x >> 6, i = (bm & 0xFFFF) * 64 + e;
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = 0.f;
+        if (i < j.len) {
+            const float* p = j.src + i;
+            int s = sg;
+            for (; s + 60 < j.nsplit; s += 64) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k] += p[(long)(s + 4 * k) * j.stride];
+            }
+            for (int k = 0; s < j.nsplit; s += 4, ++k) a[k & 15] += p[(long)s * j.stride];
+        }
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += a[k];
+        r4[sg][e] = t;
+        __syncthreads();
+        if (sg == 0 && i < j.len) {
+            const float gi0 = ((r4[0][e] + r4[1][e]) + (r4[2][e] + r4[3][e])) * j.scale;
+            j.dst[i] = gi0;
+            const long o = (j.dst - A.g) + i;
+            float wi = A.w[o], mi = A.m[o], vi = A.v[o], gi = gi0;
+            if (A.wd != 0.f) gi += A.wd * wi;
+            mi = A.b1 * mi + (1.0f - A.b1) * gi;
+            vi = A.b2 * vi + (1.0f - A.b2) * gi * gi;
+            wi -= step_size * (mi / (sqrtf(vi) / bc2s + A.eps));
+            A.w[o] = wi; A.m[o] = mi; A.v[o] = vi;
+            if (A.shadow && o >= A.shadow_from) A.shadow[o] = (unsigned short)(adam_pk_bf16(wi, 0.f) & 0xFFFFu);
+        }
+        return;
+    }
+    const long nb = gridDim.x - nblocks;
+    for (long i = (long)(blockIdx.x - nblocks) * ROW_THREADS + threadIdx.x; i < A.item_n4; i += nb * ROW_THREADS) {
+        const long o = A.item_off + 4 * i;
+        f32x4 wi = ld4(A.w + o), gi = ld4(A.g + o), mi = ld4(A.m + o), vi = ld4(A.v + o);
+        if (A.wd != 0.f) gi += A.wd * wi;
+        mi = A.b1 * mi + (1.0f - A.b1) * gi;
+        vi = A.b2 * vi + (1.0f - A.b2) * gi * gi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wi[k] -= step_size * (mi[k] / (sqrtf(vi[k]) / bc2s + A.eps));
+        st4(A.w + o, wi); st4(A.m + o, mi); st4(A.v + o, vi);
+        if (A.shadow && o >= A.shadow_from)
+            *reinterpret_cast<uint2*>(A.shadow + o) = make_uint2(adam_pk_bf16(wi.x, wi.y), adam_pk_bf16(wi.z, wi.w));
+    }
+}
+
 // fp32 -> bf16 (round to nearest even) for up to six tensors, jobs in the kernarg block: blockIdx.y = tensor
 struct CastJobs6 { const float* src[6]; unsigned short* dst[6]; long n4[6]; };
 __global__ void __launch_bounds__(ROW_THREADS)
