@@ -144,7 +144,7 @@ struct bsarec_plan {
     long red_elems; const float *red_lo, *red_hi;   // what the reduction jobs write: element count, address range
     // options resolved from cfg (0 = default there)
     int top_slabs; bool embed_in_block, direct_dw;
-    bool scatter_in_block;                     // fused path: the embedding-gradient scatter rides in the bottom block's backward
+    bool scatter_in_block;                     // fused path: the embedding-gradient scatter rides in block 0's weight-gradient launch
     ProfState prof;
     long long* stamps = nullptr;             // diagnostic stamp buffer (bsarec_debug_stamps)
     bsarec_hook_t dense_hook = nullptr; void* dense_hook_user = nullptr;   // bsarec_plan_set_dense_grad_hook
@@ -206,8 +206,8 @@ static void derive(bsarec_plan& p) {
     const int want_splits = c.splits > 0 ? c.splits : 40;
     p.top_slabs = c.top_slabs > 0 ? c.top_slabs : 2;
     p.embed_in_block = !c.separate_embed || p.bf;     // bf16 storage: X[0] is written by the block kernel only
-    p.scatter_in_block = p.fused && !c.separate_embed;
     p.direct_dw = !c.dw_tiled && (long)p.T * 4 * c.hidden * 4 < (1L << 31);      // its operands sit behind 32-bit buffer offsets
+    p.scatter_in_block = p.fused && p.direct_dw && !c.separate_embed;
     long ch = rup(cdiv(p.T, want_splits), GEMM_BK);
     if (ch < 64) ch = 64;
     if (ch > 2048) ch = 2048;
@@ -577,7 +577,6 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     if (l == 0) {       // the embedding front-end's backward (Drop + LayerNorm) rides in the bottom block's epilogue
         F.e_dz = p.dz; F.e_xhat = p.xhat0; F.e_rstd = p.rstd0; F.e_g = p.P.ln_w;
         F.e_pg = p.part_ln0; F.e_pb = p.part_ln0 + nb * d; F.e_drop = make_drop(p, c.p_hidden, 0, tr);
-        if (p.scatter_in_block) { F.e_dE = p.lookup_grad ? p.lookup_grad : p.G.item_emb; F.e_ids32 = p.ids32; }
     }
     F.dT = p.dT; F.dU = p.dU; F.dO = p.dO; F.dq = p.dq; F.dk = p.dk; F.dv = p.dv;
     F.pg_ff = p.part_ln + 0 * nb * d; F.pb_ff = p.part_ln + 1 * nb * d; F.pg_a = p.part_ln + 2 * nb * d;
@@ -1110,9 +1109,15 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                     TickP tk_here;                     // the step tick rides in block 0's launch when Adam is fused into the reduction
                     memset(&tk_here, 0, sizeof(tk_here));
                     if (fuse_adam && l == 0) tk_here = tick;
+                    ScatterP sc;                       // ... and so does the embedding-gradient scatter (block 0's launch: dz is complete)
+                    memset(&sc, 0, sizeof(sc));
+                    if (p->scatter_in_block && l == 0) {
+                        sc.de = p->dz; sc.ids32 = p->ids32; sc.T = T; sc.dE = p->lookup_grad ? p->lookup_grad : p->G.item_emb;
+                        sc.nblocks = cdiv(T, SCATTER_FLOATS / 64);
+                    }
                     ProfScope prof(BSAREC_K_DW1, s);
-                    LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * (dw_nu - DW.nsmall) + DW.nsmall * DW.small_slabs + (tk_here.state ? 1 : 0)),
-                           dim3(256), 0, s, DW, tk_here);
+                    LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * (dw_nu - DW.nsmall) + DW.nsmall * DW.small_slabs + sc.nblocks +
+                                                  (tk_here.state ? 1 : 0)), dim3(256), 0, s, DW, tk_here, sc);
                     HIPCHK(hipGetLastError());
                     dw_np = 0; dw_nu = 0; DW.nsmall = 0; DW.small_slabs = 0;
                 }

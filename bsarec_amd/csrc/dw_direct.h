@@ -206,10 +206,23 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
 // tk.state != null: one extra (last) workgroup closes the optimisation step here -- mean loss, Adam's t and bias
 // corrections, next dropout step, batch cursor (kernels.h, tick_body) -- so that the step's final kernel can reduce AND
 // update with a read-only state.  Every reader of the dropout step / cursor of this step has run before this launch.
+// sc.nblocks > 0: the lookup-path scatter of the item-table gradient (embed_scatter_block, 64-token chunks) rides here
+// too, as the workgroups after the weight-gradient ones: light, latency-bound blocks that fill the slots the big
+// workgroups leave free instead of a launch of their own (11.6 us + a launch boundary at C1).
+struct ScatterP { const float* de; const int* ids32; int T; float* dE; int nblocks; };
 __global__ void __launch_bounds__(256)
-dw_direct_kernel(const DwP G, const TickP tk) {
+dw_direct_kernel(const DwP G, const TickP tk, const ScatterP sc) {
     __shared__ __attribute__((aligned(16))) float red[3][66][64];      // accumulators (64) + bias sums (2) of waves 1..3
-    if (tk.state && blockIdx.x == gridDim.x - 1) { tick_body(tk, &red[0][0][0]); return; }
+    static_assert(sizeof(red) >= (SCATTER_FLOATS + 2 * (SCATTER_FLOATS / 64)) * 4, "scatter scratch fits the reduction scratch");
+    {
+        const int nmain = 8 * ((G.nslab + 7) >> 3) * (G.nunits - G.nsmall) + G.nsmall * G.small_slabs;
+        if ((int)blockIdx.x >= nmain) {
+            const int x = blockIdx.x - nmain;
+            if (x < sc.nblocks) embed_scatter_block<16>(sc.de, sc.ids32, sc.T, 64, sc.dE, x, &red[0][0][0]);
+            else if (tk.state) tick_body(tk, &red[0][0][0]);
+            return;
+        }
+    }
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All units of
     // one slab slice read the same token rows (X feeds the q/k/v tiles, hmix and dT2 four tiles each), so a slice is
     // kept on ONE XCD and the re-reads hit that L2.

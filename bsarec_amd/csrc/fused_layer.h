@@ -817,9 +817,6 @@ struct FusedBwdP {
     // bottom block only (e_dz != null): the embedding front-end's backward rides in the epilogue --
     // y = Drop(LN(e)) (src/model/_abstract_model.py:14-24): de = LNbwd(dX * keep/(1-p)) -> e_dz instead of dX
     float* e_dz; const float *e_xhat, *e_rstd, *e_g; float *e_pg, *e_pb; DropP e_drop;
-    // ... and so does the lookup-path scatter of the item-table gradient (padding_idx = 0 rows skipped,
-    // src/model/_abstract_model.py:10): e_dE != null -> dE[ids[t]] += de[t] with one full-row (256 B) float atomic per token
-    float* e_dE; const int* e_ids32;
 };
 
 
@@ -1343,13 +1340,6 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             lds_barrier();
         }
         f32x4 sb = {0, 0, 0, 0}, sg0 = sb, sb0 = sb;
-        float* const e_dE = KARG(FusedBwdP, e_dE);
-        int my_ids[8];                                   // ids of the rows this wave scatters (row = wave + 8 j): requested
-        if (e_dE) {                                      // now, used after the row pass
-            const int* const ids32 = KARG(FusedBwdP, e_ids32);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) my_ids[j] = gldi(ids32 + tok0 + min(wave + 8 * j, L - 1));
-        }
         float* const e_dz = KARG(FusedBwdP, e_dz);
         const float* const e_xhat = KARG(FusedBwdP, e_xhat);
         const float* const e_rstd = KARG(FusedBwdP, e_rstd);
@@ -1376,19 +1366,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                 const f32x4 gg = dx * g0;
                 const float m1 = group_sum<16>(gg.x + gg.y + gg.z + gg.w) * (1.0f / 64.0f);
                 const float m2 = group_sum<16>(gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w) * (1.0f / 64.0f);
-                const f32x4 de = rs * (gg - m1 - xh * m2);
-                if (ok) gst4(e_dz + e, de);                 // kept: the position gradient sums it over the batch
-                if (e_dE) st4(sXin + t * FS + lc, de);      // same (t, lc) this thread has just read: in place
+                if (ok) gst4(e_dz + e, rs * (gg - m1 - xh * m2));
                 sg0 += dx * xh; sb0 += dx;
-            }
-        }
-        if (e_dE) {
-            lds_barrier();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = wave + 8 * j;
-                if (r < L && my_ids[j] != 0)                // lane = column: one 256-byte atomic row add per token
-                    (void)__builtin_amdgcn_global_atomic_fadd_f32((AS_GLOBAL float*)e_dE + (long)my_ids[j] * 64 + lane, sXin[r * FS + lane]);
             }
         }
         seq_partial_64(sb, sQ, R8_pbeta + (long)b * 64, 2.0f, R8_sqrt_beta);

@@ -438,23 +438,22 @@ dlast_kernel(const float* __restrict__ slabs, int nsplit, long slab_stride, int 
 #define SCATTER_FLOATS 4096           // LDS row accumulators per block: chunk = 4096 / (4*LPR) tokens (64 at d = 64:
                                       // 200 blocks at C1; 128-token chunks measured 18.2 us, 64- and 32-token chunks 11.6 us)
 #endif
+// One scatter block: CHUNK tokens starting at chunk * CHUNK.  esm: SCATTER_FLOATS floats + 2 * CHUNK ints of LDS.
 template <int LPR>
-__global__ void __launch_bounds__(ROW_THREADS)
-embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, int B, int L, int d,
-                 float* __restrict__ dE, float* __restrict__ dPos, int scatter_blocks) {
+__device__ __forceinline__ void embed_scatter_block(const float* __restrict__ de, const int* __restrict__ ids32, int T, int d,
+                                                    float* __restrict__ dE, int chunk, float* __restrict__ esm) {
     constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4, CHUNK = SCATTER_FLOATS / W;
-    extern __shared__ __attribute__((aligned(16))) float esm[];
-    float* acc = esm;                                   // [CHUNK][W]   (also the dPos reduction scratch)
+    float* acc = esm;                                   // [CHUNK][W]
     int* sid = reinterpret_cast<int*>(esm + SCATTER_FLOATS);      // [CHUNK]
     int* lead = sid + CHUNK;                                      // [CHUNK]
     const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
     const bool colok = lc < d;
-    if ((int)blockIdx.x < scatter_blocks) {
+    {
         // Popular items (Zipf) would serialise hundreds of global float atomics on one row.  Each block
         // owns CHUNK tokens: every token finds the first occurrence of its id in the chunk (its leader),
         // all rows are folded into the leader's LDS row with LDS atomics, and each leader then issues ONE
         // global atomic row add (>= 64 B contiguous per row).
-        const int T = B * L, t0 = blockIdx.x * CHUNK;
+        const int t0 = chunk * CHUNK;
         const int n = min(CHUNK, T - t0);
         for (int i = threadIdx.x; i < CHUNK; i += ROW_THREADS) sid[i] = i < n ? ids32[t0 + i] : 0;
         for (int i = threadIdx.x; i < SCATTER_FLOATS / 4; i += ROW_THREADS) st4(acc + 4 * i, f32x4{0, 0, 0, 0});
@@ -503,6 +502,19 @@ embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, in
             for (int c0 = 0; c0 < d; c0 += 64)
                 if (c0 + lane < d) unsafeAtomicAdd(dE + row + c0 + lane, acc[j * W + c0 + lane]);
         }
+    }
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(ROW_THREADS)
+embed_bwd_kernel(const float* __restrict__ de, const int* __restrict__ ids32, int B, int L, int d,
+                 float* __restrict__ dE, float* __restrict__ dPos, int scatter_blocks) {
+    constexpr int RPP = ROW_THREADS / LPR, W = LPR * 4;
+    extern __shared__ __attribute__((aligned(16))) float esm[];
+    const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
+    const bool colok = lc < d;
+    if ((int)blockIdx.x < scatter_blocks) {
+        embed_scatter_block<LPR>(de, ids32, B * L, d, dE, blockIdx.x, esm);
         return;
     }
     float (*red)[W] = reinterpret_cast<float (*)[W]>(esm);
