@@ -5,6 +5,6 @@ Host API mirrors the reference (Sun-Sir/BSARec): ``BSARecModel(args)`` with ``fo
 ``train`` / ``valid`` / ``test``.  All arithmetic runs in ``libbsarec_hip.so`` (C ABI in
 ``include/bsarec_hip.h``); there is no CPU or PyTorch fallback.
 """
-from .model import BSARecModel, SASRecModel, FMLPRecModel, MODEL_DICT, param_shapes  # noqa: F401
+from .model import BSARecModel, SASRecModel, FMLPRecModel, DuoRecModel, MODEL_DICT, param_shapes  # noqa: F401
 
-__all__ = ["BSARecModel", "SASRecModel", "FMLPRecModel", "MODEL_DICT", "param_shapes"]
+__all__ = ["BSARecModel", "SASRecModel", "FMLPRecModel", "DuoRecModel", "MODEL_DICT", "param_shapes"]

@@ -130,6 +130,7 @@ EXPORTS = {
     "bsarec_loss_logsig": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_logits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bsarec_backward_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_adam_step": (C.c_int, [C.POINTER(Adam), C.c_void_p, C.c_void_p]),
     "bsarec_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Adam), C.c_void_p]),
     "bsarec_gather_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int,

@@ -136,6 +136,7 @@ struct bsarec_plan {
     bool prune_ok;                             // the loss path may run the pruned top block (fused shape, >= 2 layers)
     bool pruned;                               // mode of the last forward
     int loss_kind;                             // head of the last loss call: 0 = full-catalogue CE, 1 = SASRec's BCE pair
+    const float* ext_dy = nullptr;             // bsarec_backward_seq: upstream gradient of the last layer's output, all positions
     const int64_t *bce_pos, *bce_neg;
     float *part_kvb, *slab_dummy;
     float* part_cwL[BSAREC_MAX_LAYERS];        // FMLPRec: per-sequence d(complex_weight) [B][cb][d][2]
@@ -859,6 +860,17 @@ extern "C" int bsarec_backward(bsarec_plan_t* p, void* stream) {
     return backward_impl(p, stream, none);
 }
 
+extern "C" int bsarec_backward_seq(bsarec_plan_t* p, const float* d_out, void* stream) {
+    if (!p || !d_out) return -10;
+    if (p->pruned) return -13;                 // the forward kept only the last row of the top block: run bsarec_forward
+    TickP none;
+    memset(&none, 0, sizeof(none));
+    p->ext_dy = d_out;
+    const int rc = backward_impl(p, stream, none);
+    p->ext_dy = nullptr;
+    return rc;
+}
+
 // Can the final gradient reduction and Adam be one launch (reduce_adam_kernel)?  Needs the direct weight-gradient
 // launch of block 0 to host the step tick, plain single-GPU gradient sources, and every gradient tensor inside the flat
 // arena the update walks (item table + the reduction jobs' targets = the whole arena).
@@ -884,10 +896,12 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
     const SlabMap sm = slab_map(d);
     const int ns = p->nsplit, nb = p->nblk;
     const float* hlast = p->X[N] + (long)(L - 1) * d;
-    const bool direct_logits = p->fused && p->direct_dw && p->loss_kind == 0 && (long)B * p->Vp * 4 < (1L << 30) &&
+    const bool direct_logits = !p->ext_dy && p->fused && p->direct_dw && p->loss_kind == 0 && (long)B * p->Vp * 4 < (1L << 30) &&
                                (long)c.item_size * d * 4 < (1L << 31);
 
-    if (p->loss_kind == 1) {     // SASRec's BCE pair: two embedding rows per sequence instead of the dense logits path
+    if (p->ext_dy) {             // backward of forward(): no head on this path, the item table gets its lookup rows only
+        if (!g_dry) HIPCHK(hipMemsetAsync(p->G.item_emb, 0, (size_t)c.item_size * d * sizeof(float), s));
+    } else if (p->loss_kind == 1) {     // SASRec's BCE pair: two embedding rows per sequence instead of the dense logits path
         if (!g_dry) HIPCHK(hipMemsetAsync(p->G.item_emb, 0, (size_t)c.item_size * d * sizeof(float), s));
         LAUNCH(bce_bwd_kernel, dim3(B), dim3(64), 0, s, hlast, (long)L * d, p->P.item_emb, p->bce_pos, p->bce_neg, p->dlogits, B, d,
                c.item_size, p->dlast_slab, p->G.item_emb);
@@ -933,8 +947,17 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
         }
     }
     // the dense item-table gradient is complete (enqueued): a data-parallel host may start exchanging it now
-    if (p->dense_hook && !g_dry) p->dense_hook(p->dense_hook_user, stream);
+    if (p->dense_hook && !g_dry && !p->ext_dy) p->dense_hook(p->dense_hook_user, stream);
     float* dY = (N & 1) ? p->dXb : p->dXa;       // gradient w.r.t. X[l+1]; ping-pong so that dX[0] lands in dXa
+    if (p->ext_dy) {
+        if (p->bf) {      // the block kernels read inter-block gradients as bf16: convert the caller's fp32 tensor once
+            CastJobs6 J;
+            memset(&J, 0, sizeof(J));
+            J.src[0] = p->ext_dy; J.dst[0] = (unsigned short*)dY; J.n4[0] = (long)T * d / 4;
+            LAUNCH(cast_bf16_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS), 1), dim3(ROW_THREADS), 0, s, J);
+            HIPCHK(hipGetLastError());
+        } else dY = const_cast<float*>(p->ext_dy);
+    } else
     if (!p->fused) {      // the fused top-layer backward synthesises this gradient from the slabs itself
         LAUNCH(dlast_kernel, dim3(cdiv((long)T * d / 4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, p->dlast_slab,
                p->loss_kind == 1 ? 1 : p->vsplit, (long)B * d, T, L, d, dY);
@@ -954,7 +977,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
         if (top_pruned) {
             RET(launch_top_bwd(*p, l, tr, dXout, s));
         } else if (p->fused) {
-            RET(launch_fused_bwd(*p, l, tr, dY, dXout, s, l == N - 1));
+            RET(launch_fused_bwd(*p, l, tr, dY, dXout, s, l == N - 1 && !p->ext_dy));
         } else {
         // ---- FeedForward backward
         {
@@ -1053,7 +1076,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
             // Top block: only position L-1 of each sequence carries an upstream gradient (bsarec.py:32), so dq, dO, dU
             // and dT2 are zero on every other row: their four products reduce over the B last positions only
             // (row stride L*ld), exactly; dk and dv still reduce over all tokens.
-            const bool top = (l == N - 1);
+            const bool top = (l == N - 1) && !p->ext_dy;       // (an external upstream gradient has every row)
             for (int i = 0; i < 6; ++i) {
                 const bool last_only = top && i != 1 && i != 2;
                 GemmP g = gemm_defaults(sp[i].M, sp[i].N, last_only ? B : T);

@@ -140,6 +140,35 @@ class DeviceBatches:
         assert nbad == 0, "negative sampling did not converge (catalogue smaller than a prefix?)"
         return neg
 
+    def enable_same_target(self):
+        """Semantic augmentation of the contrastive sibling models (DuoRec): for every training sample another training
+        sequence with the SAME target item (src/dataset.py:41-56,82-96), drawn per batch on the device.  The reference
+        draws ``random.choice`` among the sequences of that target and re-draws while it got the sample's own items and
+        the group holds anything else; here: a uniform member of the group, stepped to the next member when it is the
+        sample itself and the group has more than one."""
+        order = torch.argsort(self.answers, stable=True)
+        sorted_ans = self.answers[order]
+        uniq, counts = torch.unique_consecutive(sorted_ans, return_counts=True)
+        V = int(self.answers.max().item()) + 1
+        self._st_order = order
+        self._st_start = torch.zeros(V, dtype=torch.int64, device=self.device)
+        self._st_count = torch.zeros(V, dtype=torch.int64, device=self.device)
+        self._st_start[uniq] = torch.cumsum(counts, 0) - counts
+        self._st_count[uniq] = counts
+        self._st_gen = torch.Generator(device=self.device)
+        self._st_gen.manual_seed(self.seed + 104729)
+        return self
+
+    def sample_same_target(self, idx: torch.Tensor) -> torch.Tensor:
+        ans = self.answers[idx]
+        start, cnt = self._st_start[ans], self._st_count[ans]
+        r = (torch.rand(idx.shape, device=self.device, generator=self._st_gen) * cnt).long().clamp_(max=cnt.max() - 1)
+        r = torch.minimum(r, cnt - 1)
+        pick = self._st_order[start + r]
+        own = (pick == idx) & (cnt > 1)
+        pick = torch.where(own, self._st_order[start + (r + 1) % cnt], pick)
+        return self.inputs[pick]
+
     def __len__(self):
         g = self.batch_size * self.world
         n = self.answers.shape[0]
@@ -179,5 +208,6 @@ class DeviceBatches:
                 idx = shard_of_global_batch(idx, self.batch_size, self.rank, self.world)
             users, ins, ans = self.users[idx], self.inputs[idx], self.answers[idx]
             neg = self.sample_negatives(ins, ans) if self._neg_V is not None else self._empty
-            yield (users, ins, ans, neg, self._empty.view(0))
+            same = self.sample_same_target(idx) if getattr(self, "_st_order", None) is not None else self._empty.view(0)
+            yield (users, ins, ans, neg, same)
         self.epoch += 1

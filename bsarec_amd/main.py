@@ -58,6 +58,12 @@ def parse_args(argv=None):
     p.add_argument("--initializer_range", default=0.02, type=float)
     p.add_argument("--c", default=3, type=int)
     p.add_argument("--alpha", default=0.9, type=float)
+    # DuoRec's flags (src/utils.py:106-111)
+    p.add_argument("--tau", default=1.0, type=float)
+    p.add_argument("--lmd", default=0.1, type=float)
+    p.add_argument("--lmd_sem", default=0.1, type=float)
+    p.add_argument("--ssl", default="us_x", type=str)
+    p.add_argument("--sim", default="dot", type=str)
     return p.parse_args(argv)
 
 
@@ -101,6 +107,8 @@ def run(args, user_seq, logger=None, checkpoint_path=None):
     model = MODEL_DICT[args.model_type.lower()](args=args)
     if getattr(model, "needs_negatives", False):
         train_dl.enable_negatives(user_seq, args.item_size)
+    if getattr(model, "needs_same_target", False):
+        train_dl.enable_same_target()
     model.set_seed(args.seed)
     trainer = Trainer(model, train_dl, eval_dl, test_dl, args, logger)
     if args.do_eval:

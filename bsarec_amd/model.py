@@ -67,7 +67,7 @@ def _twiddle(Lq: int) -> torch.Tensor:
 class _Plan:
     """One launch plan (fixed batch size) + the workspace tensor it carves."""
 
-    def __init__(self, model: "BSARecModel", batch: int, garena=None):
+    def __init__(self, model: "BSARecModel", batch: int, garena=None, own_state: bool = False):
         lib = L.load()
         a = model.args
         self.cfg = L.Config(batch, a.max_seq_length, a.hidden_size, a.num_attention_heads, a.num_hidden_layers,
@@ -96,9 +96,12 @@ class _Plan:
         pt, gt = model._tensor_struct(model._arena), model._tensor_struct(self.garena)
         st = model._tensor_struct(model._shadow_arena()) if self.bf16 else None
         stream = torch.cuda.current_stream(dev).cuda_stream
+        # own_state: a snapshot of the model's step state (dropout seed / step) that stays put while OTHER forwards run --
+        # a forward retained for autograd must regenerate ITS masks in its backward
+        self.state = torch.zeros_like(model._state) if own_state else model._state
         L.check(lib.bsarec_plan_create(C.byref(self.handle), C.byref(self.cfg), C.byref(pt), C.byref(gt),
                                        C.byref(st) if st is not None else None,
-                                       self.ws.data_ptr(), nbytes, model._state.data_ptr(),
+                                       self.ws.data_ptr(), nbytes, self.state.data_ptr(),
                                        model._twiddle.data_ptr(), stream), "bsarec_plan_create")
         self.lib = lib
 
@@ -119,6 +122,49 @@ class _Plan:
                 self.lib.bsarec_plan_destroy(self.handle)
         except Exception:
             pass
+
+
+class _SlotToken:
+    """Holds one retained-forward plan slot; released by the backward, or when autograd drops the graph."""
+
+    def __init__(self, model, key):
+        self.model, self.key = model, key
+
+    def release(self):
+        if self.key is not None:
+            self.model._slots_busy.discard(self.key)
+            self.key = None
+
+    def __del__(self):
+        self.release()
+
+
+class _SeqFn(torch.autograd.Function):
+    """BSARecModel.forward as an autograd node (src/model/bsarec.py:16-28): the last layer's output on all positions,
+    differentiable w.r.t. every parameter.  Each call keeps its own plan (activations + a snapshot of the dropout
+    step) until its backward ran, so several forwards can be alive in one graph (DuoRec's three, duorec.py:95-127)."""
+
+    @staticmethod
+    def forward(ctx, model, ids, *params):
+        B = ids.shape[0]
+        slot = 1
+        while (B, slot) in model._slots_busy:
+            slot += 1
+        model._slots_busy.add((B, slot))
+        ctx.token = _SlotToken(model, (B, slot))
+        plan = model._run_forward(ids, train=model.training, new_step=model.training, slot=slot)
+        ctx.model, ctx.plan = model, plan
+        N, Lq, d = model.args.num_hidden_layers, model.args.max_seq_length, model.args.hidden_size
+        return plan.view(L.BUF_LAYER_OUT, N, (B, Lq, d)).clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, plan = ctx.model, ctx.plan
+        g = gout.to(torch.float32).contiguous()
+        L.check(plan.lib.bsarec_backward_seq(plan.handle, g.data_ptr(), model._stream()), "bsarec_backward_seq")
+        grads = model._garena.clone()
+        ctx.token.release()
+        return (None, None) + model._grads_in_param_order(grads)
 
 
 class _LossFn(torch.autograd.Function):
@@ -172,6 +218,7 @@ class BSARecModel(nn.Module):
         self._install_arena(arena)
         self.init_weights()
         self._plans: Dict[Tuple[int, str], _Plan] = {}
+        self._slots_busy = set()
         self._seed = int(getattr(args, "seed", 42))
 
     # ---- module tree with the reference's parameter paths -------------------------------------
@@ -323,15 +370,17 @@ class BSARecModel(nn.Module):
         s = (int(seed) ^ (rank * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
         self._state[0] = s
 
-    def _plan(self, batch: int, parity: int = 0) -> _Plan:
+    def _plan(self, batch: int, parity: int = 0, slot: int = 0) -> _Plan:
         self._require_gpu()
         opts = L.default_options()
         opts.update(self.options)
-        key = (batch, str(self._arena.device), tuple(sorted(opts.items())), parity)
+        key = (batch, str(self._arena.device), tuple(sorted(opts.items())), parity, slot)
         if key not in self._plans:
             if int(self._state[0].item()) == 0:
                 self.set_seed(self._seed)
-            if parity == 0:
+            if slot > 0:        # a retained forward of the autograd API: own workspace, own snapshot of the step state
+                self._plans[key] = _Plan(self, batch, own_state=True)
+            elif parity == 0:
                 self._plans[key] = _Plan(self, batch)
             else:       # the other gradient arena; its own workspace (the reduction job table inside it names the arena)
                 self._plans[key] = _Plan(self, batch, garena=self._garena_alt)
@@ -342,15 +391,20 @@ class BSARecModel(nn.Module):
     def _stream(self):
         return torch.cuda.current_stream(self._arena.device).cuda_stream
 
-    def _run_forward(self, input_ids, train: bool, new_step: bool, last_only: bool = False) -> _Plan:
+    def _run_forward(self, input_ids, train: bool, new_step: bool, last_only: bool = False, slot: int = 0) -> _Plan:
         if input_ids.dim() != 2 or input_ids.shape[1] != self.args.max_seq_length:
             raise ValueError("input_ids must be [B, max_seq_length]")
         ids = input_ids.to(device=self._arena.device, dtype=torch.int64).contiguous()
-        plan = self._plan(ids.shape[0])
+        plan = self._plan(ids.shape[0], slot=slot)
         lib, st = plan.lib, self._stream()
         if new_step:
-            L.check(lib.bsarec_step_begin(plan.handle, st), "bsarec_step_begin")
+            if slot:
+                self._state[1:2].add_(1)     # (the plan of a retained forward has a private state: advance the model's)
+            else:
+                L.check(lib.bsarec_step_begin(plan.handle, st), "bsarec_step_begin")
             self._step_begun = True          # the counter now holds a value in use (see _fresh_step_counter)
+        if slot:
+            plan.state.copy_(self._state)    # this forward's own dropout step, whatever runs before its backward
         # the eager API may follow an update of the masters this module cannot see (torch.optim over model.parameters()):
         # always rebuild the bf16 shadow here (storage = 1 only; one small launch per layer)
         self._refresh_shadow(plan, force=True)
@@ -379,10 +433,19 @@ class BSARecModel(nn.Module):
 
     # ---- reference model API --------------------------------------------------------------------
     def forward(self, input_ids, user_ids=None, all_sequence_output=False):
-        """src/model/bsarec.py:16-28.  Returns detached tensors (copies of the workspace buffers);
-        gradients flow through :meth:`calculate_loss`."""
-        plan = self._run_forward(input_ids, train=self.training, new_step=self.training)
+        """src/model/bsarec.py:16-28.  With autograd enabled the LAST layer's output is differentiable w.r.t. every
+        parameter (an autograd node over bsarec_forward / bsarec_backward_seq); the intermediate layer outputs of
+        ``all_sequence_output=True`` are returned detached.  :meth:`calculate_loss` stays the fast path of the trainer."""
         B, Lq, d = input_ids.shape[0], self.args.max_seq_length, self.args.hidden_size
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            last = _SeqFn.apply(self, input_ids, *self.parameters())
+            if not all_sequence_output:
+                return last
+            plan = last.grad_fn.plan if hasattr(last.grad_fn, "plan") else None
+            lower = [plan.view(L.BUF_LAYER_OUT, l, (B, Lq, d)).float().clone() for l in range(self.args.num_hidden_layers)] \
+                if plan is not None else []
+            return lower + [last]
+        plan = self._run_forward(input_ids, train=self.training, new_step=self.training)
         if all_sequence_output:
             return [plan.view(L.BUF_LAYER_OUT, l, (B, Lq, d)).float().clone() for l in range(self.args.num_hidden_layers + 1)]
         return plan.view(L.BUF_LAYER_OUT, self.args.num_hidden_layers, (B, Lq, d)).clone()
@@ -675,5 +738,75 @@ class FMLPRecModel(BSARecModel):
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
 
 
+class DuoRecModel(SASRecModel):
+    """Sibling model: ``MODEL_DICT['duorec']``, src/model/duorec.py.  The encoder is SASRec's
+    TransformerEncoder (a BSARec plan with alpha = 0, same 36 state_dict keys); the loss is the full-catalogue CE of the
+    last position plus InfoNCE terms between the last-position outputs of up to three forward passes of one step --
+    the input, the input again under another dropout draw, and a same-target sequence (duorec.py:95-127).  The three
+    passes are three live nodes of the differentiable :meth:`forward` (each keeps its own activations and dropout step
+    until its backward); the head itself -- two small matmuls and a softmax over 2B x 2B similarities -- is the
+    reference's torch code restated, on the device."""
+
+    needs_negatives = False
+    needs_same_target = True                     # Trainer / DeviceBatches: feed same_target rows (src/dataset.py:82-96)
+    torch_optim = True                           # several backward passes accumulate through autograd: torch.optim.Adam steps
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.tau = float(getattr(args, "tau", 1.0))
+        self.ssl = getattr(args, "ssl", "us_x")
+        self.sim = getattr(args, "sim", "dot")
+        self.lmd = float(getattr(args, "lmd", 0.1))
+        self.lmd_sem = float(getattr(args, "lmd_sem", 0.1))
+
+    @staticmethod
+    def _mask_correlated(batch_size, device):
+        n = 2 * batch_size
+        mask = torch.ones((n, n), dtype=torch.bool, device=device)
+        mask.fill_diagonal_(False)
+        idx = torch.arange(batch_size, device=device)
+        mask[idx, batch_size + idx] = False
+        mask[batch_size + idx, idx] = False
+        return mask
+
+    def info_nce(self, z_i, z_j, temp, batch_size, sim="dot"):
+        """duorec.py:47-78: positives = the two views of a sequence, negatives = the other 2(B - 1) rows of the batch."""
+        n = 2 * batch_size
+        z = torch.cat((z_i, z_j), dim=0)
+        if sim == "cos":
+            s = torch.nn.functional.cosine_similarity(z.unsqueeze(1), z.unsqueeze(0), dim=2) / temp
+        else:
+            s = torch.mm(z, z.T) / temp
+        pos = torch.cat((torch.diag(s, batch_size), torch.diag(s, -batch_size)), dim=0).reshape(n, 1)
+        neg = s[self._mask_correlated(batch_size, z.device)].reshape(n, -1)
+        labels = torch.zeros(n, dtype=torch.long, device=z.device)
+        return torch.cat((pos, neg), dim=1), labels
+
+    def calculate_loss(self, input_ids, answers, neg_answers=None, same_target=None, user_ids=None):
+        """src/model/duorec.py:95-127."""
+        ce = torch.nn.functional.cross_entropy
+        B = input_ids.shape[0]
+        seq_output = self.forward(input_ids)[:, -1, :]
+        logits = torch.matmul(seq_output, self.item_embeddings.weight.transpose(0, 1))
+        loss = ce(logits, answers.to(logits.device))
+        if self.ssl in ("us", "un"):
+            aug = self.forward(input_ids)[:, -1, :]
+            lg, lb = self.info_nce(seq_output, aug, self.tau, B, self.sim)
+            loss = loss + self.lmd * ce(lg, lb)
+        if self.ssl in ("us", "su"):
+            sem = self.forward(same_target)[:, -1, :]
+            lg, lb = self.info_nce(seq_output, sem, self.tau, B, self.sim)
+            loss = loss + self.lmd_sem * ce(lg, lb)
+        if self.ssl == "us_x":
+            aug = self.forward(input_ids)[:, -1, :]
+            sem = self.forward(same_target)[:, -1, :]
+            lg, lb = self.info_nce(aug, sem, self.tau, B, self.sim)
+            loss = loss + self.lmd_sem * ce(lg, lb)
+        return loss
+
+    def train_step(self, input_ids, answers, neg_answers=None, same_target=None):
+        raise RuntimeError("DuoRec steps through calculate_loss / backward / torch.optim.Adam (Trainer does)")
+
+
 # src/model/__init__.py:10-19: the hot-path entry and its siblings on the same kernels
-MODEL_DICT = {"bsarec": BSARecModel, "sasrec": SASRecModel, "fmlprec": FMLPRecModel}
+MODEL_DICT = {"bsarec": BSARecModel, "sasrec": SASRecModel, "fmlprec": FMLPRecModel, "duorec": DuoRecModel}

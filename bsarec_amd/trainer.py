@@ -337,6 +337,7 @@ class Trainer:
 
     def iteration(self, epoch, dataloader, train=True):
         pairwise = getattr(self.model, "needs_negatives", False)       # sibling models with a pos / neg loss head (SASRec)
+        pairwise = pairwise or getattr(self.model, "torch_optim", False)
         if train and isinstance(dataloader, DeviceBatches) and not pairwise:
             self.model.train()
             loss_sum, nb = self._epoch_indexed(dataloader)
@@ -355,8 +356,23 @@ class Trainer:
             nb = 0
             for batch in dataloader:
                 batch = tuple(t.to(self.device, non_blocking=True) for t in batch)
-                _, input_ids, answers, neg_answers, _ = batch
-                if pairwise:
+                user_ids, input_ids, answers, neg_answers, same_target = batch
+                if getattr(self.model, "torch_optim", False):
+                    # sibling models whose loss combines several forward passes (DuoRec): the reference's own loop --
+                    # calculate_loss / zero_grad / backward / Adam.step over model.parameters() (src/trainers.py:103-107);
+                    # every forward / backward is the HIP path, the optimiser walks the arena views
+                    if self.dp:
+                        raise NotImplementedError("data parallel is built for the BSARec step only")
+                    if getattr(self, "_torch_opt", None) is None:
+                        self._torch_opt = torch.optim.Adam(self.model.parameters(), lr=self.args.lr,
+                                                           betas=(self.args.adam_beta1, self.args.adam_beta2),
+                                                           weight_decay=self.args.weight_decay)
+                    loss = self.model.calculate_loss(input_ids, answers, neg_answers, same_target, user_ids)
+                    self._torch_opt.zero_grad()
+                    loss.backward()
+                    self._torch_opt.step()
+                    loss = loss.detach()
+                elif pairwise:
                     if self.dp:
                         raise NotImplementedError("data parallel is built for the BSARec step only")
                     loss = self.model.train_step(input_ids, answers, neg_answers)

@@ -175,6 +175,13 @@ int bsarec_logits(bsarec_plan_t *plan, void *stream);
  * accumulated).  Must follow bsarec_forward(train as given there) + bsarec_loss on the same plan. */
 int bsarec_backward(bsarec_plan_t *plan, void *stream);
 
+/* Backward of BSARecModel.forward itself (src/model/bsarec.py:16-28 as an autograd graph): `d_out` = gradient w.r.t.
+ * the LAST layer's output on ALL positions, fp32 [B, L, d].  Must follow bsarec_forward (not _forward_last) on the
+ * same plan.  Gradients of all tensors -> `grads` (overwritten); the item table receives its lookup-path rows only
+ * (there is no logits product on this path).  What sibling models with their own heads on the sequence output need
+ * (DuoRec's contrastive terms, src/model/duorec.py:95-127). */
+int bsarec_backward_seq(bsarec_plan_t *plan, const float *d_out, void *stream);
+
 /* torch.optim.Adam (src/trainers.py:27-28,107) over flat arenas: one struct for every entry point that updates. */
 typedef struct {
     float *params;            /* [n] fp32 master parameters (n % 4 == 0) */
