@@ -227,15 +227,20 @@ def test_config4_shape_large_batch_and_catalogue_runs_and_learns():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
-def test_config5_scale_catalogue_ten_million_items_properties():
+@pytest.mark.parametrize("shape", ["d64_L50_N1", "C5_d256_L256_N2"])
+def test_config5_scale_catalogue_ten_million_items_properties(shape):
     """BASELINE config 5's catalogue (V = 10,000,001; logits rows of 40 MB, B*V > 2^31 elements) through the same
-    entry points: the loss equals a float64 log-sum-exp recomputed from the encoder output in catalogue chunks,
-    every dlogits row sums to zero (so do the untouched-by-lookup columns of dE), sampled dE rows equal
-    dlogits^T . h_last, and one Adam step moves exactly the rows that received gradient.  Size-independent
-    properties only: the numpy oracle does not run at this size."""
+    entry points -- at the fused shape class (d = 64, L = 50, 1 layer) and at C5's OWN shape (L = 256,
+    hidden 256, 4 heads, 2 layers, B = 256: generic tiled kernels, a 10.24 GB fp32 table with 41 GB of parameter +
+    gradient + Adam state, 10 GB logits rows streamed by the CE kernel): the loss equals a float64 log-sum-exp recomputed
+    from the encoder output in catalogue chunks, every dlogits row sums to zero (so do the untouched-by-lookup columns of
+    dE), sampled dE rows equal dlogits^T . h_last, and one Adam step moves exactly the rows that received gradient.
+    Size-independent properties only: the numpy oracle does not run at this size."""
     from bsarec_amd import BSARecModel, _lib as Lb
-    V, B, Lq, d = 10_000_001, 256, 50, 64
-    a = ns(item_size=V, num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    V, B = 10_000_001, 256
+    Lq, d, N, heads = (50, 64, 1, 2) if shape == "d64_L50_N1" else (256, 256, 2, 4)
+    a = ns(item_size=V, num_hidden_layers=N, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, hidden_size=d,
+           max_seq_length=Lq, num_attention_heads=heads)
     torch.manual_seed(3)
     model = BSARecModel(a).cuda()
     model.train()
@@ -247,7 +252,8 @@ def test_config5_scale_catalogue_ten_million_items_properties():
     ans[:4] = torch.tensor([1, V - 1, V - 2, 5_000_000], device="cuda")         # catalogue edges
     loss = model.calculate_loss(ids, ans)
     loss.backward()
-    h = model.forward(ids)[:, -1, :].double()                                    # dropout off: same activations
+    with torch.no_grad():
+        h = model.forward(ids)[:, -1, :].double()                                # dropout off: same activations
     E = model.item_embeddings.weight.detach()
     m = torch.full((B,), -1e30, dtype=torch.float64, device="cuda"); ssum = torch.zeros_like(m)
     for v0 in range(0, V, 1_000_000):
@@ -268,7 +274,7 @@ def test_config5_scale_catalogue_ten_million_items_properties():
     probe = torch.tensor([0, 7, 123_457, 4_999_999, 9_999_999, V - 1], device="cuda")
     probe = probe[~torch.isin(probe, ids.flatten())]                              # rows without a lookup gradient
     want = dlog[:, probe].double().T @ h
-    assert float((dE[probe].double() - want).abs().max().item()) <= 1e-5 * float(want.abs().max().item())   # fp32 sum over 256 rows
+    assert float((dE[probe].double() - want).abs().max().item()) <= 2e-5 * float(want.abs().max().item())   # fp32 sum over 256 rows
     # lookup rows: dE[row] - logits part = sum of the embedding-path gradient rows of that id (non-zero for used ids)
     used = torch.unique(ids[ids > 0])[:64]
     lookup = dE[used].double() - dlog[:, used].double().T @ h
