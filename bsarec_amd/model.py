@@ -433,11 +433,11 @@ class BSARecModel(nn.Module):
 
     # ---- reference model API --------------------------------------------------------------------
     def forward(self, input_ids, user_ids=None, all_sequence_output=False):
-        """src/model/bsarec.py:16-28.  With autograd enabled the LAST layer's output is differentiable w.r.t. every
+        """src/model/bsarec.py:16-28.  In train mode with autograd enabled the LAST layer's output is differentiable w.r.t. every
         parameter (an autograd node over bsarec_forward / bsarec_backward_seq); the intermediate layer outputs of
         ``all_sequence_output=True`` are returned detached.  :meth:`calculate_loss` stays the fast path of the trainer."""
         B, Lq, d = input_ids.shape[0], self.args.max_seq_length, self.args.hidden_size
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             last = _SeqFn.apply(self, input_ids, *self.parameters())
             if not all_sequence_output:
                 return last

@@ -63,7 +63,7 @@ def test_hip_fmlprec_vs_reference_golden(name):
     m = m.cuda()
     m.train()
     ids, pos, neg = (torch.from_numpy(z[k]).cuda() for k in ("ids", "pos", "neg"))
-    outs = m.forward(ids, all_sequence_output=True)
+    outs = [o.detach() for o in m.forward(ids, all_sequence_output=True)]
     for i, o in enumerate(outs):
         assert np.abs(o.cpu().numpy() - z[f"out/{i}"]).max() <= 2e-5, i
     loss = m.calculate_loss(ids, pos, neg, None, None)

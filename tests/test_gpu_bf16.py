@@ -61,7 +61,7 @@ def test_bf16_forward_loss_grads_vs_reference_golden():
     model = build(cfg, params)
     model.train()
     ids = torch.from_numpy(z["ids"]).cuda()
-    outs = model.forward(ids, all_sequence_output=True)
+    outs = [o.detach() for o in model.forward(ids, all_sequence_output=True)]
     real = z["ids"] > 0
     for l, o in enumerate(outs):
         r = z[f"out/{l}"]

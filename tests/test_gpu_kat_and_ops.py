@@ -139,8 +139,8 @@ def test_full_size_properties_batch_equivariance_and_normalisation():
     model.eval()
     t = torch.from_numpy(ids).cuda()
     perm = torch.randperm(256, device="cuda")
-    a = model.forward(t)
-    b = model.forward(t[perm])
+    a = model.forward(t).detach()
+    b = model.forward(t[perm]).detach()
     assert torch.equal(a[perm], b)
     plan = model._plan(256)
     probs = plan.view(Lb.BUF_PROBS, 0, (256, 2, 50, 52))

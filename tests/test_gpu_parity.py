@@ -63,7 +63,7 @@ def test_forward_loss_grads_vs_reference_golden(name):
     model.train()                                        # golden was made in train mode with p = 0
     ids = torch.from_numpy(z["ids"]).cuda()
     ans = torch.from_numpy(z["answers"]).cuda()
-    outs = model.forward(ids, all_sequence_output=True)
+    outs = [o.detach() for o in model.forward(ids, all_sequence_output=True)]
     check_outputs(outs, [z[f"out/{i}"] for i in range(len(outs))], z["ids"], 2e-5, 5e-4)
     logits = model.full_logits(ids).cpu().numpy()
     assert np.abs(logits - z["logits"]).max() <= 1e-3 * np.abs(z["logits"]).max()      # north-star gate
@@ -155,8 +155,8 @@ def test_eval_mode_ignores_dropout_and_is_deterministic():
     assert torch.equal(a, b)
     np.testing.assert_allclose(a.cpu().numpy()[z["ids"] > 0], z[f"out/{cfg.num_hidden_layers}"][z["ids"] > 0], atol=2e-5)
     model.train()
-    c = model.forward(ids)
-    d = model.forward(ids)
+    c = model.forward(ids).detach()
+    d = model.forward(ids).detach()
     assert not torch.equal(c, d)                         # new step -> new masks
 
 
