@@ -126,7 +126,10 @@ __device__ __forceinline__ void dw_issue(DwStage<BF>& st, __amdgpu_buffer_rsrc_t
     }
 }
 
-struct CeLoop { const float* s_lse; const int* s_ans; int col0, V, rows; float scale; };    // col0: this lane's first column
+// (LDS pointers carry their address space: through a generic pointer these reads become flat_load, which counts on vmcnt
+// AND lgkmcnt -- every read would first drain the whole global prefetch pipeline)
+#define AS_LDS __attribute__((address_space(3)))
+struct CeLoop { const AS_LDS float* s_lse; const AS_LDS int* s_ans; int col0, V, rows; float scale; };    // col0: this lane's first column
 template <bool GELU, bool MASK, bool BF, bool CE = false>
 __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob, int soa, int sob,
                                         int rowa, int rowb, int nkb, int crow, int kend, f32x16 (&acc)[2][2], f32x2& bs,
@@ -216,7 +219,7 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
             else dw_loop<false, true, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
         }
         if (Q.ce) {                                      // the dE problem of the logits backward with the CE folded in (fp32, no GELU)
-            const CeLoop ce{s_lse, s_ans, m0 + 2 * l31, Q.M, Q.K, Q.ce_scale};
+            const CeLoop ce{(const AS_LDS float*)s_lse, (const AS_LDS int*)s_ans, m0 + 2 * l31, Q.M, Q.K, Q.ce_scale};
             dw_loop<false, true, false, true>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs, ce);
         } else if (Q.bf16) { DW_RUN(true) } else { DW_RUN(false) }
 #undef DW_RUN
@@ -323,8 +326,8 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg, const float* 
     const int kbeg = split * G.kchunk, kend = min(G.V, kbeg + G.kchunk);
     const int nkb = kend > kbeg ? ((kend - kbeg + 8 * DW_STAGES - 1) / (8 * DW_STAGES)) * DW_STAGES : 0;
     const int m = min(32 * mt + l31, G.B - 1);                       // rows past B re-read the last row; never stored
-    const float lse_m = G.ce ? s_lse[m] : 0.f;
-    const int ans_m = G.ce ? s_ans[m] : 0;
+    const float lse_m = G.ce ? ((const AS_LDS float*)s_lse)[m] : 0.f;
+    const int ans_m = G.ce ? ((const AS_LDS int*)s_ans)[m] : 0;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
