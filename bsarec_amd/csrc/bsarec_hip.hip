@@ -139,7 +139,7 @@ struct bsarec_plan {
     const float* ext_dy = nullptr;             // bsarec_backward_seq: upstream gradient of the last layer's output, all positions
     bool ce_in_bwd = false;                    // the last loss call left logits + per-tile statistics: the backward folds the CE in
     const int64_t* ce_answers = nullptr;
-    float *ce_pmax = nullptr, *ce_psum = nullptr;   // [ceil(V/32)][B] per-tile row maxima / exp-sums (fused shape)
+    float *ce_pmax = nullptr, *ce_psum = nullptr;   // [ceil(V/64)][B] per-tile row maxima / exp-sums (fused shape)
     const int64_t *bce_pos, *bce_neg;
     float *part_kvb, *slab_dummy;
     float* part_cwL[BSAREC_MAX_LAYERS];        // FMLPRec: per-sequence d(complex_weight) [B][cb][d][2]
@@ -245,7 +245,7 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
         b.u = cv.take<float>(4 * Td); b.xhat_ff = cv.take<float>(Td); b.rstd_ff = cv.take<float>(T);
     }
     p.logits = cv.take<float>(B * p.Vp); p.dlogits = cv.take<float>(B * p.Vp);
-    if (p.fused) { p.ce_pmax = cv.take<float>((long)cdiv(c.item_size, 32) * B); p.ce_psum = cv.take<float>((long)cdiv(c.item_size, 32) * B); }
+    if (p.fused) { p.ce_pmax = cv.take<float>((long)cdiv(c.item_size, 64) * B); p.ce_psum = cv.take<float>((long)cdiv(c.item_size, 64) * B); }
     p.loss_rows = cv.take<float>(B); p.loss = cv.take<float>(4);
     p.dXa = cv.take<float>(Td); p.dXb = cv.take<float>(Td); p.dz = cv.take<float>(Td); p.dT = cv.take<float>(Td);
     p.dU = cv.take<float>(4 * Td); p.dH = cv.take<float>(Td); p.dXacc = cv.take<float>(Td); p.dO = cv.take<float>(Td);
@@ -833,7 +833,7 @@ static int loss_head_fused(bsarec_plan_t* p, const int64_t* answers, hipStream_t
     memset(&P, 0, sizeof(P));
     P.h = p->X[c.layers] + (long)(L - 1) * d; P.ldh = (long)L * d; P.E = p->P.item_emb; P.B = c.batch; P.V = c.item_size;
     P.ldl = p->Vp; P.logits = p->logits; P.pmax = p->ce_pmax; P.psum = p->ce_psum;
-    const int units = cdiv(c.batch, 32) * cdiv(c.item_size, 32);
+    const int units = cdiv(c.batch, 32) * cdiv(c.item_size, 64);
     {
         ProfScope prof(BSAREC_K_LOGITS, s);
         LAUNCH(logits_stats_kernel, dim3(cdiv(units, 4)), dim3(256), 0, s, P);
@@ -952,7 +952,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
         if (p->ce_in_bwd) {       // the operand is the logits buffer; d loss / d logits is formed while loading
             q.A = p->logits; q.ce = 1; q.ce_scale = 1.0f / (float)B;
             H.A = p->logits; H.ce = 1; H.ce_scale = q.ce_scale;
-            C.pmax = p->ce_pmax; C.psum = p->ce_psum; C.ntile = cdiv(c.item_size, 32); C.B = B; C.V = c.item_size;
+            C.pmax = p->ce_pmax; C.psum = p->ce_psum; C.ntile = cdiv(c.item_size, 64); C.B = B; C.V = c.item_size;
             C.answers = p->ce_answers; C.logits = p->logits; C.ldl = p->Vp; C.loss_rows = p->loss_rows;
         }
         const int tiles = cdiv(c.item_size, 64);

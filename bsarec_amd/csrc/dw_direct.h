@@ -53,24 +53,26 @@ struct CeP {
     float* loss_rows;                         // [B] (written by workgroup 0)
 };
 __device__ __forceinline__ void ce_prologue(const CeP& C, float* __restrict__ s_lse, int* __restrict__ s_ans) {
+    // one thread per batch row; 16 tiles' (max, sum) pairs in flight per step (a rolled loop would pay one L2 round trip
+    // per tile: 2 x 107 dependent trips were 16 us), combined online: m' = max(m, pm), s = s e^(m - m') + ps e^(pm - m')
     for (int b = threadIdx.x; b < C.B; b += blockDim.x) {
-        float m = -INFINITY;
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int t = 0;
-        for (; t + 3 < C.ntile; t += 4) {
+        float m = -INFINITY, sum = 0.f;
+        for (int t0 = 0; t0 < C.ntile; t0 += 16) {
+            float pm[16], ps[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) mx[k] = fmaxf(mx[k], C.pmax[(long)(t + k) * C.B + b]);
-        }
-        for (; t < C.ntile; ++t) mx[0] = fmaxf(mx[0], C.pmax[(long)t * C.B + b]);
-        m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-        float sm[4] = {0.f, 0.f, 0.f, 0.f};
-        t = 0;
-        for (; t + 3 < C.ntile; t += 4) {
+            for (int k = 0; k < 16; ++k) {
+                const int t = min(t0 + k, C.ntile - 1);                 // branch-free: the tail re-reads the last tile, weight 0
+                pm[k] = C.pmax[(long)t * C.B + b]; ps[k] = C.psum[(long)t * C.B + b];
+            }
+            float mm = m;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sm[k] += C.psum[(long)(t + k) * C.B + b] * expf(C.pmax[(long)(t + k) * C.B + b] - m);
+            for (int k = 0; k < 16; ++k) mm = fmaxf(mm, pm[k]);
+            float acc = sum * expf(m - mm);                             // m = -inf at the start: exp(-inf) = 0
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += (t0 + k < C.ntile ? ps[k] : 0.f) * expf(pm[k] - mm);
+            m = mm; sum = acc;
         }
-        for (; t < C.ntile; ++t) sm[0] += C.psum[(long)t * C.B + b] * expf(C.pmax[(long)t * C.B + b] - m);
-        const float lse = m + logf((sm[0] + sm[1]) + (sm[2] + sm[3]));
+        const float lse = m + logf(sum);
         int a = (int)C.answers[b];
         a = a < 0 ? 0 : (a >= C.V ? C.V - 1 : a);
         s_lse[b] = lse; s_ans[b] = a;
@@ -388,9 +390,9 @@ logits_bwd_direct_kernel(const DwProblem Q, int tiles, const DhP H, const CeP C)
 
 // =============================================================================================
 // logits = h_last . E^T at hidden = 64 (src/model/bsarec.py:33-34) with the cross-entropy statistics as its epilogue:
-// one wave per (32-item tile, 32-row tile), operands straight from global memory (K = 64: eight 16-byte loads per
+// one wave per (64-item tile, 32-row tile), operands straight from global memory (K = 64: eight 16-byte loads per
 // lane and operand).  Computed transposed -- A = E rows (lane = item), B = h rows (lane = batch row) -- so that the
-// accumulator has the batch row on the lane and the 32 items in registers: the row maximum and the exp-sum of the
+// accumulators have the batch row on the lane and the 64 items in registers: the row maximum and the exp-sum of the
 // tile are register reductions plus one cross-half exchange.  Writes logits [B][ldl] (pad columns 0) and the per-tile
 // (max, sum exp(x - max)) pair of every row; the backward combines them (ce_prologue).
 // =============================================================================================
@@ -402,46 +404,58 @@ struct LogitsStatsP {
 };
 __global__ void __launch_bounds__(256)
 logits_stats_kernel(const LogitsStatsP P) {
+    // one wave = 64 items (two 32-item accumulators sharing the h fragment) x 32 batch rows; statistic tiles of 64 items
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-    const int mtiles = (P.B + 31) >> 5, ntiles = (P.V + 31) >> 5;
+    const int mtiles = (P.B + 31) >> 5, ntiles = (P.V + 63) >> 6;
     const int unit = blockIdx.x * 4 + wv, nt = unit / mtiles, mt = unit - nt * mtiles;
     if (nt >= ntiles) return;
-    const int item = min(32 * nt + l31, P.V - 1), brow = min(32 * mt + l31, P.B - 1);
-    const float* ea = P.E + (long)item * 64 + 4 * half;
+    const int brow = min(32 * mt + l31, P.B - 1);
     const float* hb = P.h + (long)brow * P.ldh + 4 * half;
-    f32x4 a[8], b[8];
+    const float* ea0 = P.E + (long)min(64 * nt + l31, P.V - 1) * 64 + 4 * half;
+    const float* ea1 = P.E + (long)min(64 * nt + 32 + l31, P.V - 1) * 64 + 4 * half;
+    f32x4 a0[8], a1[8], b[8];
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) { a[kb] = gld4(ea + 8 * kb); b[kb] = gld4(hb + 8 * kb); }
-    f32x16 acc;
+    for (int kb = 0; kb < 8; ++kb) { b[kb] = gld4(hb + 8 * kb); a0[kb] = gld4(ea0 + 8 * kb); a1[kb] = gld4(ea1 + 8 * kb); }
+    f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kb][s], b[kb][s], acc, 0, 0, 0);
-    // lane = batch row 32 mt + l31; register r = item 32 nt + rho(r) + 4 half
+        for (int s = 0; s < 4; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kb][s], b[kb][s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kb][s], b[kb][s], acc[1], 0, 0, 0);
+        }
+    // lane = batch row 32 mt + l31; register r of accumulator i = item 64 nt + 32 i + rho(r) + 4 half
     float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int v = 32 * nt + rho(r) + 4 * half;
-        if (v >= P.V) acc[r] = 0.f;                        // pad columns of the logits buffer are 0
-        else mx = fmaxf(mx, acc[r]);
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = 64 * nt + 32 * i + rho(r) + 4 * half;
+            if (v >= P.V) acc[i][r] = 0.f;                 // pad columns of the logits buffer are 0
+            else mx = fmaxf(mx, acc[i][r]);
+        }
     mx = xor32_max(mx);
     float sm = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int v = 32 * nt + rho(r) + 4 * half;
-        if (v < P.V) sm += expf(acc[r] - mx);
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int v = 64 * nt + 32 * i + rho(r) + 4 * half;
+            if (v < P.V) sm += expf(acc[i][r] - mx);
+        }
     sm = xor32_sum(sm);
     const int bi = 32 * mt + l31;
     if (bi < P.B) {
-        float* out = P.logits + (long)bi * P.ldl + 32 * nt + 4 * half;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (32 * nt + 8 * g + 4 * half < P.ldl) gst4(out + 8 * g, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]});
+        for (int i = 0; i < 2; ++i) {
+            float* out = P.logits + (long)bi * P.ldl + 64 * nt + 32 * i + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (64 * nt + 32 * i + 8 * g + 4 * half < P.ldl)
+                    gst4(out + 8 * g, f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]});
+        }
         if (half == 0) { gst(P.pmax + (long)nt * P.B + bi, mx); gst(P.psum + (long)nt * P.B + bi, sm); }
     }
 }
-
