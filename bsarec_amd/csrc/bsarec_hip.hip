@@ -137,9 +137,6 @@ struct bsarec_plan {
     bool pruned;                               // mode of the last forward
     int loss_kind;                             // head of the last loss call: 0 = full-catalogue CE, 1 = SASRec's BCE pair
     const float* ext_dy = nullptr;             // bsarec_backward_seq: upstream gradient of the last layer's output, all positions
-    bool ce_in_bwd = false;                    // the last loss call left logits + per-tile statistics: the backward folds the CE in
-    const int64_t* ce_answers = nullptr;
-    float *ce_pmax = nullptr, *ce_psum = nullptr;   // [ceil(V/64)][B] per-tile row maxima / exp-sums (fused shape)
     const int64_t *bce_pos, *bce_neg;
     float *part_kvb, *slab_dummy;
     float* part_cwL[BSAREC_MAX_LAYERS];        // FMLPRec: per-sequence d(complex_weight) [B][cb][d][2]
@@ -245,7 +242,6 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
         b.u = cv.take<float>(4 * Td); b.xhat_ff = cv.take<float>(Td); b.rstd_ff = cv.take<float>(T);
     }
     p.logits = cv.take<float>(B * p.Vp); p.dlogits = cv.take<float>(B * p.Vp);
-    if (p.fused) { p.ce_pmax = cv.take<float>((long)cdiv(c.item_size, 64) * B); p.ce_psum = cv.take<float>((long)cdiv(c.item_size, 64) * B); }
     p.loss_rows = cv.take<float>(B); p.loss = cv.take<float>(4);
     p.dXa = cv.take<float>(Td); p.dXb = cv.take<float>(Td); p.dz = cv.take<float>(Td); p.dT = cv.take<float>(Td);
     p.dU = cv.take<float>(4 * Td); p.dH = cv.take<float>(Td); p.dXacc = cv.take<float>(Td); p.dO = cv.take<float>(Td);
@@ -816,37 +812,11 @@ extern "C" int bsarec_logits(bsarec_plan_t* p, void* stream) {
     return launch_gemm<64, 64, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, no_xform(), e, nullptr, 1, s, BSAREC_K_LOGITS);
 }
 
-// The training step's head at the fused shape: logits + per-tile CE statistics in one launch; the cross-entropy itself
-// (lse, loss rows, d loss / d logits) is folded into the logits backward (dw_direct.h, CeP).  BSAREC_BUF_DLOGITS is
-// not written on this path.
-static bool head_fusable(const bsarec_plan& p) {
-    const bsarec_config_t& c = p.cfg;
-    return p.fused && p.direct_dw && c.batch <= CE_MAX_B && (long)c.batch * p.Vp * 4 < (1L << 30) &&
-           (long)c.item_size * c.hidden * 4 < (1L << 31);
-}
-static int loss_head_fused(bsarec_plan_t* p, const int64_t* answers, hipStream_t s) {
-    if (!p || !answers) return -10;
-    PlanScope scope(p);
-    const bsarec_config_t& c = p->cfg;
-    const int d = c.hidden, L = c.seq_len;
-    LogitsStatsP P;
-    memset(&P, 0, sizeof(P));
-    P.h = p->X[c.layers] + (long)(L - 1) * d; P.ldh = (long)L * d; P.E = p->P.item_emb; P.B = c.batch; P.V = c.item_size;
-    P.ldl = p->Vp; P.logits = p->logits; P.pmax = p->ce_pmax; P.psum = p->ce_psum;
-    const int units = cdiv(c.batch, 32) * cdiv(c.item_size, 64);
-    {
-        ProfScope prof(BSAREC_K_LOGITS, s);
-        LAUNCH(logits_stats_kernel, dim3(cdiv(units, 4)), dim3(256), 0, s, P);
-    }
-    p->loss_kind = 0; p->ce_in_bwd = true; p->ce_answers = answers;
-    return (int)hipGetLastError();
-}
-
 static int loss_impl(bsarec_plan_t* p, const int64_t* answers, void* stream, bool with_mean) {
     if (!p || !answers) return -10;
     hipStream_t s = (hipStream_t)stream;
     RET(bsarec_logits(p, stream));
-    p->loss_kind = 0; p->ce_in_bwd = false;
+    p->loss_kind = 0;
     const bsarec_config_t& c = p->cfg;
     LAUNCH(ce_rows_kernel, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, c.item_size, p->Vp,
                        1.0f / (float)c.batch, p->dlogits, p->loss_rows);
@@ -873,7 +843,7 @@ static int loss_pair(bsarec_plan_t* p, const int64_t* pos_ids, const int64_t* ne
     hipStream_t s = (hipStream_t)stream;
     const bsarec_config_t& c = p->cfg;
     const int L = c.seq_len, d = c.hidden;
-    p->loss_kind = 1; p->bce_pos = pos_ids; p->bce_neg = neg_ids; p->ce_in_bwd = false;
+    p->loss_kind = 1; p->bce_pos = pos_ids; p->bce_neg = neg_ids;
     LAUNCH(bce_rows_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->X[c.layers] + (long)(L - 1) * d, (long)L * d, p->P.item_emb,
            pos_ids, neg_ids, c.batch, d, c.item_size, p->dlogits, p->loss, logsig);
     return (int)hipGetLastError();
@@ -947,16 +917,8 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
         memset(&H, 0, sizeof(H));
         H.A = p->dlogits; H.lda = p->Vp; H.E = p->P.item_emb; H.B = B; H.V = c.item_size; H.kchunk = p->vchunk;
         H.nsplit = p->vsplit; H.slab = p->dlast_slab;
-        CeP C;
-        memset(&C, 0, sizeof(C));
-        if (p->ce_in_bwd) {       // the operand is the logits buffer; d loss / d logits is formed while loading
-            q.A = p->logits; q.ce = 1; q.ce_scale = 1.0f / (float)B;
-            H.A = p->logits; H.ce = 1; H.ce_scale = q.ce_scale;
-            C.pmax = p->ce_pmax; C.psum = p->ce_psum; C.ntile = cdiv(c.item_size, 64); C.B = B; C.V = c.item_size;
-            C.answers = p->ce_answers; C.logits = p->logits; C.ldl = p->Vp; C.loss_rows = p->loss_rows;
-        }
         const int tiles = cdiv(c.item_size, 64);
-        LAUNCH(logits_bwd_direct_kernel, dim3(tiles + cdiv(cdiv(B, 32) * p->vsplit, 4)), dim3(256), 0, s, q, tiles, H, C);
+        LAUNCH(logits_bwd_direct_kernel, dim3(tiles + cdiv(cdiv(B, 32) * p->vsplit, 4)), dim3(256), 0, s, q, tiles, H);
         HIPCHK(hipGetLastError());
     } else
     // dE (dense, logits path) = dlogits^T . h_last  [V, d] (overwrites the gradient buffer) and the split-K slabs of
@@ -1313,8 +1275,7 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
     if (!table || !answers_table || !perm || !cursor || !ids_buf || !answers_buf) return -10;
     GatherP gp{table, answers_table, perm, n_samples, (const long long*)cursor, ids_buf, answers_buf};
     RET(forward_impl(p, ids_buf, 1, stream, gp, true));       // batch assembly rides in the embedding kernel
-    if (head_fusable(*p)) RET(loss_head_fused(p, answers_buf, s));      // 8 launches: no CE kernel, no dlogits round trip
-    else RET(loss_impl(p, answers_buf, stream, false));
+    RET(loss_impl(p, answers_buf, stream, false));
     // the extra block of the final gradient reduction closes the step: mean loss, Adam t and bias corrections, next
     // forward-step index, cursor += B
     const TickP tk = make_tick(p->state, 1, a->lr, a->beta1, a->beta2, p->loss_rows, p->cfg.batch, p->loss, cursor, p->cfg.batch, 1);
@@ -1330,13 +1291,8 @@ extern "C" int bsarec_grad_step_indexed(bsarec_plan_t* p, const int64_t* table, 
     if (!p || !table || !answers_table || !perm || !cursor || !ids_buf || !answers_buf) return -10;
     GatherP gp{table, answers_table, perm, n_samples, (const long long*)cursor, ids_buf, answers_buf};
     RET(forward_impl(p, ids_buf, 1, stream, gp, true));
-    // same convention as bsarec_train_step_indexed: the step index / cursor advance when the step is done
-    if (head_fusable(*p)) {       // CE folded into the logits backward; the step's closing block forms the mean loss
-        RET(loss_head_fused(p, answers_buf, (hipStream_t)stream));
-        return backward_impl(p, stream, make_tick(p->state, lr > 0.f ? 1 : 0, lr, b1, b2, p->loss_rows, p->cfg.batch, p->loss, cursor,
-                                                  p->cfg.batch, 1));
-    }
     RET(bsarec_loss(p, answers_buf, stream));
+    // same convention as bsarec_train_step_indexed: the step index / cursor advance when the step is done
     return backward_impl(p, stream, make_tick(p->state, lr > 0.f ? 1 : 0, lr, b1, b2, nullptr, 0, nullptr, cursor, p->cfg.batch, 1));
 }
 

@@ -36,53 +36,7 @@ struct DwProblem {
     int gelu;                           // erf-GELU on the activation operand while loading (dW2 = dT2^T . gelu(u))
     int bf16;                           // both operands are bf16 tensors (cfg.storage = 1): lda / ldb still count elements; the
                                         // products stay fp32 MFMA on the widened values (the kernel is bound by operand bytes)
-    int ce;                             // the gradient operand holds LOGITS [K = batch rows][M = catalogue]: d loss / d logits =
-    float ce_scale;                     // (exp(x - lse[row]) - [col == answer[row]]) * ce_scale is formed while loading (CeP)
 };
-
-// Cross-entropy folded into the logits backward (src/model/bsarec.py:35 + its autograd): the logits kernel leaves
-// per-(32-item tile, row) maxima and exp-sums; every workgroup of the backward combines them into lse[row] in LDS
-// (ce_prologue) and turns logits into d loss / d logits on the way into the MFMA operands -- no CE launch, no dlogits
-// round trip through memory.
-#define CE_MAX_B 1024
-struct CeP {
-    const float* pmax; const float* psum;     // [ntile][B]
-    int ntile, B, V;
-    const int64_t* answers;                   // [B]
-    const float* logits; long ldl;            // [B][ldl]
-    float* loss_rows;                         // [B] (written by workgroup 0)
-};
-__device__ __forceinline__ void ce_prologue(const CeP& C, float* __restrict__ s_lse, int* __restrict__ s_ans) {
-    // one thread per batch row; 16 tiles' (max, sum) pairs in flight per step (a rolled loop would pay one L2 round trip
-    // per tile: 2 x 107 dependent trips were 16 us), combined online: m' = max(m, pm), s = s e^(m - m') + ps e^(pm - m')
-    for (int b = threadIdx.x; b < C.B; b += blockDim.x) {
-        float m = -INFINITY, sum = 0.f;
-        for (int t0 = 0; t0 < C.ntile; t0 += 16) {
-            float pm[16], ps[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int t = min(t0 + k, C.ntile - 1);                 // branch-free: the tail re-reads the last tile, weight 0
-                pm[k] = C.pmax[(long)t * C.B + b]; ps[k] = C.psum[(long)t * C.B + b];
-            }
-            float mm = m;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) mm = fmaxf(mm, pm[k]);
-            float acc = sum * expf(m - mm);                             // m = -inf at the start: exp(-inf) = 0
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc += (t0 + k < C.ntile ? ps[k] : 0.f) * expf(pm[k] - mm);
-            m = mm; sum = acc;
-        }
-        const float lse = m + logf(sum);
-        int a = (int)C.answers[b];
-        a = a < 0 ? 0 : (a >= C.V ? C.V - 1 : a);
-        s_lse[b] = lse; s_ans[b] = a;
-        if (blockIdx.x == 0) C.loss_rows[b] = lse - C.logits[(long)b * C.ldl + a];
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ float ce_grad(float x, float lse, int ans, int col, int V, float scale) {
-    return col < V ? (expf(x - lse) - (col == ans ? 1.0f : 0.0f)) * scale : 0.f;
-}
 
 struct DwUnit { short prob, m0, n0, pad; };
 
@@ -128,14 +82,9 @@ __device__ __forceinline__ void dw_issue(DwStage<BF>& st, __amdgpu_buffer_rsrc_t
     }
 }
 
-// (LDS pointers carry their address space: through a generic pointer these reads become flat_load, which counts on vmcnt
-// AND lgkmcnt -- every read would first drain the whole global prefetch pipeline)
-#define AS_LDS __attribute__((address_space(3)))
-struct CeLoop { const AS_LDS float* s_lse; const AS_LDS int* s_ans; int col0, V, rows; float scale; };    // col0: this lane's first column
-template <bool GELU, bool MASK, bool BF, bool CE = false>
+template <bool GELU, bool MASK, bool BF>
 __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob, int soa, int sob,
-                                        int rowa, int rowb, int nkb, int crow, int kend, f32x16 (&acc)[2][2], f32x2& bs,
-                                        const CeLoop ce = CeLoop{}) {
+                                        int rowa, int rowb, int nkb, int crow, int kend, f32x16 (&acc)[2][2], f32x2& bs) {
     DwStage<BF> st[DW_STAGES];
 #pragma unroll
     for (int u = 0; u < DW_STAGES; ++u) {
@@ -151,13 +100,6 @@ __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buff
                 f32x2 a, b;
                 if constexpr (BF) { a = f32x2{bf_lo(cur.a[s]), bf_hi(cur.a[s])}; b = f32x2{bf_lo(cur.b[s]), bf_hi(cur.b[s])}; }
                 else { a = cur.a[s]; b = cur.b[s]; }
-                if constexpr (CE) {            // logits -> d loss / d logits of batch row crow + s (rows past the batch: masked below)
-                    const int row = min(crow + s, ce.rows - 1);
-                    const float l = ce.s_lse[row];
-                    const int an = ce.s_ans[row];
-                    a.x = ce_grad(a.x, l, an, ce.col0, ce.V, ce.scale);
-                    a.y = ce_grad(a.y, l, an, ce.col0 + 1, ce.V, ce.scale);
-                }
                 if (MASK) {
                     const bool ok = crow + s < kend;
                     a.x = ok ? a.x : 0.f; a.y = ok ? a.y : 0.f; b.x = ok ? b.x : 0.f; b.y = ok ? b.y : 0.f;
@@ -183,8 +125,7 @@ __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buff
 
 // One workgroup = one (problem, 64 x 64 tile, slab slice): its 4 waves take the 4 quarters of the slice, meet in LDS,
 // wave 0 writes the slab.
-__device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, int slab, float (*red)[66][64],
-                                           const float* s_lse = nullptr, const int* s_ans = nullptr) {
+__device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, int slab, float (*red)[66][64]) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     // this wave's quarter of the slab slice
@@ -220,10 +161,7 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
             if (full) dw_loop<false, false, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
             else dw_loop<false, true, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
         }
-        if (Q.ce) {                                      // the dE problem of the logits backward with the CE folded in (fp32, no GELU)
-            const CeLoop ce{(const AS_LDS float*)s_lse, (const AS_LDS int*)s_ans, m0 + 2 * l31, Q.M, Q.K, Q.ce_scale};
-            dw_loop<false, true, false, true>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs, ce);
-        } else if (Q.bf16) { DW_RUN(true) } else { DW_RUN(false) }
+        if (Q.bf16) { DW_RUN(true) } else { DW_RUN(false) }
 #undef DW_RUN
     }
     // bias gradient: column sums of the gradient operand; the two lane halves hold different token rows
@@ -312,14 +250,13 @@ dw_direct_kernel(const DwP G, const TickP tk, const ScatterP sc) {
 // tiles (column 2 l31 + j).  Slab [split][B][64]; the consumer (top block backward) adds the splits.
 // =============================================================================================
 struct DhP {
-    const float* A; long lda;          // dlogits [B][lda] (ce != 0: the logits, turned into dlogits while loading)
+    const float* A; long lda;          // dlogits [B][lda]
     const float* E;                    // [V][64]
     int B, V, kchunk, nsplit;          // kchunk: catalogue columns per split, multiple of 8
     float* slab;                       // [nsplit][B][64]
-    int ce; float ce_scale;
 };
 
-__device__ __forceinline__ void dh_wave_body(const DhP& G, int wg, const float* s_lse = nullptr, const int* s_ans = nullptr) {
+__device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     const int mtiles = (G.B + 31) >> 5;
@@ -328,8 +265,6 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg, const float* 
     const int kbeg = split * G.kchunk, kend = min(G.V, kbeg + G.kchunk);
     const int nkb = kend > kbeg ? ((kend - kbeg + 8 * DW_STAGES - 1) / (8 * DW_STAGES)) * DW_STAGES : 0;
     const int m = min(32 * mt + l31, G.B - 1);                       // rows past B re-read the last row; never stored
-    const float lse_m = G.ce ? ((const AS_LDS float*)s_lse)[m] : 0.f;
-    const int ans_m = G.ce ? ((const AS_LDS int*)s_ans)[m] : 0;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -353,9 +288,7 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg, const float* 
             for (int u = 0; u < DW_STAGES; ++u) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    float a = sa[u][s];
-                    if (G.ce) a = ce_grad(a, lse_m, ans_m, ccol + s, G.V, G.ce_scale);
-                    a = ccol + s < kend ? a : 0.f;                         // columns past the slice (other splits' / next row's data)
+                    const float a = ccol + s < kend ? sa[u][s] : 0.f;      // columns past the slice (other splits' / next row's data)
                     const f32x2 b = sb[u][s];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc1, 0, 0, 0);
@@ -379,83 +312,9 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg, const float* 
 // dense gradient of the item table, written straight into the gradient buffer: problem Q, 64-row tiles, rows >= M not
 // stored), the rest form the split-K slabs of d(h_last).
 __global__ void __launch_bounds__(256)
-logits_bwd_direct_kernel(const DwProblem Q, int tiles, const DhP H, const CeP C) {
+logits_bwd_direct_kernel(const DwProblem Q, int tiles, const DhP H) {
     __shared__ __attribute__((aligned(16))) float red[3][66][64];
-    __shared__ float s_lse[CE_MAX_B];
-    __shared__ int s_ans[CE_MAX_B];
-    if (Q.ce) ce_prologue(C, s_lse, s_ans);              // every workgroup: lse / answer of all batch rows -> LDS
-    if ((int)blockIdx.x < tiles) dw_wg_body(Q, 64 * (int)blockIdx.x, 0, 0, red, s_lse, s_ans);
-    else dh_wave_body(H, (int)blockIdx.x - tiles, s_lse, s_ans);
+    if ((int)blockIdx.x < tiles) dw_wg_body(Q, 64 * (int)blockIdx.x, 0, 0, red);
+    else dh_wave_body(H, (int)blockIdx.x - tiles);
 }
 
-// =============================================================================================
-// logits = h_last . E^T at hidden = 64 (src/model/bsarec.py:33-34) with the cross-entropy statistics as its epilogue:
-// one wave per (64-item tile, 32-row tile), operands straight from global memory (K = 64: eight 16-byte loads per
-// lane and operand).  Computed transposed -- A = E rows (lane = item), B = h rows (lane = batch row) -- so that the
-// accumulators have the batch row on the lane and the 64 items in registers: the row maximum and the exp-sum of the
-// tile are register reductions plus one cross-half exchange.  Writes logits [B][ldl] (pad columns 0) and the per-tile
-// (max, sum exp(x - max)) pair of every row; the backward combines them (ce_prologue).
-// =============================================================================================
-struct LogitsStatsP {
-    const float* h; long ldh;          // h_last rows [B][ldh]
-    const float* E;                    // [V][64]
-    int B, V; long ldl;
-    float* logits; float* pmax; float* psum;       // [B][ldl]; [ntile][B] each
-};
-__global__ void __launch_bounds__(256)
-logits_stats_kernel(const LogitsStatsP P) {
-    // one wave = 64 items (two 32-item accumulators sharing the h fragment) x 32 batch rows; statistic tiles of 64 items
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-    const int mtiles = (P.B + 31) >> 5, ntiles = (P.V + 63) >> 6;
-    const int unit = blockIdx.x * 4 + wv, nt = unit / mtiles, mt = unit - nt * mtiles;
-    if (nt >= ntiles) return;
-    const int brow = min(32 * mt + l31, P.B - 1);
-    const float* hb = P.h + (long)brow * P.ldh + 4 * half;
-    const float* ea0 = P.E + (long)min(64 * nt + l31, P.V - 1) * 64 + 4 * half;
-    const float* ea1 = P.E + (long)min(64 * nt + 32 + l31, P.V - 1) * 64 + 4 * half;
-    f32x4 a0[8], a1[8], b[8];
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) { b[kb] = gld4(hb + 8 * kb); a0[kb] = gld4(ea0 + 8 * kb); a1[kb] = gld4(ea1 + 8 * kb); }
-    f32x16 acc[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[kb][s], b[kb][s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kb][s], b[kb][s], acc[1], 0, 0, 0);
-        }
-    // lane = batch row 32 mt + l31; register r of accumulator i = item 64 nt + 32 i + rho(r) + 4 half
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int v = 64 * nt + 32 * i + rho(r) + 4 * half;
-            if (v >= P.V) acc[i][r] = 0.f;                 // pad columns of the logits buffer are 0
-            else mx = fmaxf(mx, acc[i][r]);
-        }
-    mx = xor32_max(mx);
-    float sm = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int v = 64 * nt + 32 * i + rho(r) + 4 * half;
-            if (v < P.V) sm += expf(acc[i][r] - mx);
-        }
-    sm = xor32_sum(sm);
-    const int bi = 32 * mt + l31;
-    if (bi < P.B) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float* out = P.logits + (long)bi * P.ldl + 64 * nt + 32 * i + 4 * half;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (64 * nt + 32 * i + 8 * g + 4 * half < P.ldl)
-                    gst4(out + 8 * g, f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]});
-        }
-        if (half == 0) { gst(P.pmax + (long)nt * P.B + bi, mx); gst(P.psum + (long)nt * P.B + bi, sm); }
-    }
-}

@@ -233,47 +233,3 @@ def test_dropout_step_counter_is_never_reused_across_the_epoch_tail():
         tr.train(ep)
     assert len(used) == 3 * 4
     assert all(b > a for a, b in zip(used, used[1:])), used
-
-
-@pytest.mark.parametrize("B,V,heads", [(37, 211, 2), (256, 3417, 2), (5, 97, 1)])
-def test_indexed_step_with_the_cross_entropy_folded_into_the_logits_backward_vs_oracle(B, V, heads):
-    """The indexed training step's head at the fused shape: logits + per-tile (max, exp-sum) statistics in one launch,
-    lse / loss rows / d loss / d logits formed inside the logits backward (no CE kernel, no dlogits buffer).  Loss and
-    all 42 gradients of bsarec_grad_step_indexed against the oracle, dropout on (shared Philox masks); ragged batch,
-    catalogue sizes that are not multiples of the 32-item statistic tiles, and the C1 shape."""
-    from oracle import bsarec_oracle as O
-    from bsarec_amd import BSARecModel, _lib as Lb
-    from test_gpu_parity import check_grads
-    L = 50
-    cfg = O.Config(item_size=V, hidden_size=64, max_seq_length=L, num_hidden_layers=2, num_attention_heads=heads, c=3, alpha=0.9,
-                   hidden_dropout_prob=0.5, attention_probs_dropout_prob=0.5)
-    params = O.init_params(cfg, seed=B)
-    rng = np.random.default_rng(B)
-    ids = np.zeros((B, L), dtype=np.int64)
-    for b in range(B):
-        n = 0 if b == 0 else (L if b == 1 else int(rng.integers(1, L + 1)))
-        if n:
-            ids[b, L - n:] = rng.integers(1, V, size=n)
-    ans = rng.integers(1, V, size=B).astype(np.int64)
-    ans[0], ans[-1] = V - 1, 1                                 # catalogue edges (last statistic tile, first tile)
-    m = BSARecModel(ns(item_size=V, num_attention_heads=heads))
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
-    m = m.cuda()
-    m.train()
-    m.set_seed(321)
-    m.configure_adam()
-    table, ans_t = torch.from_numpy(ids).cuda(), torch.from_numpy(ans).cuda()
-    perm = torch.arange(B, device="cuda")
-    cursor = torch.zeros(1, dtype=torch.int64, device="cuda")
-    step = int(m._state[1].item())
-    loss = m.grad_step_indexed(table, ans_t, perm, cursor, B)
-    oloss, ologits, G, _ = O.loss_and_grads(params, cfg, ids, ans, O.DropoutSpec(True, 321, step))
-    assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss), (loss.item(), oloss)
-    plan = m._plan(B)
-    logits = plan.view(Lb.BUF_LOGITS, 0, (B, (V + 3) // 4 * 4)).cpu().numpy()
-    assert np.abs(logits[:, :V] - ologits).max() <= 1e-3 * np.abs(ologits).max()
-    assert np.all(logits[:, V:] == 0.0)
-    rows = plan.view(Lb.BUF_LOSS_ROWS, 0, (B,)).cpu().numpy()
-    assert abs(rows.mean() - oloss) <= 5e-6 * abs(oloss)
-    check_grads(m, G, tol=2e-4)
-    assert int(cursor.item()) == B and int(m._state[1].item()) == step + 1
