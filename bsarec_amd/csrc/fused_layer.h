@@ -837,6 +837,33 @@ __device__ __forceinline__ void seq_partial_64(const f32x4& v, float* __restrict
 }
 
 
+// N such partials with ONE pair of barriers (the one-at-a-time form costs two barriers per vector: eight in the
+// mix / LayerNorm stage alone): vector i goes through red + i * 2048, thread (i, c) = (tid >> 6, tid & 63) sums column c.
+template <int N>
+__device__ __forceinline__ void seq_partials_64(const f32x4 (&v)[N], float* const (&red)[N], float* const (&dst)[N],
+                                                float scale0 = 1.f, const float* __restrict__ mul0 = nullptr) {
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
+    const int ng = blockDim.x >> 4;
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < N; ++i) st4(red[i] + lr * 64 + lc, v[i]);
+    lds_barrier();
+    const int i = threadIdx.x >> 6, c = threadIdx.x & 63;
+    if (i < N) {
+        const float* r = red[0];
+        float* d = dst[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) if (i == k) { r = red[k]; d = dst[k]; }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int g = 0; g < ng; g += 4) {
+            s0 += r[g * 64 + c]; s1 += r[(g + 1) * 64 + c]; s2 += r[(g + 2) * 64 + c]; s3 += r[(g + 3) * 64 + c];
+        }
+        float sum = (s0 + s1) + (s2 + s3);
+        if (i == 0) { if (mul0) sum *= gld(mul0 + c); sum *= scale0; }
+        gst(d + c, sum);
+    }
+}
+
 // Backward: 8 waves = 2 groups of 4, two waves per SIMD.  dU splits its four 64-wide blocks across the groups;
 // dH, dC and the QKV input-gradient split K (two partial tiles, summed by the next row pass); attention backward
 // runs (query tile, key tile) per wave and the 6 dQ/dK/dV tiles of a head on 6 of the 8 waves; the two DFT
@@ -949,8 +976,12 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             st4(sAcc + r * FS + lc, dz);
             st4(sT + r * FS + lc, dt);
         }
-        seq_partial_64(sg, sPm, R1_pg_ff + (long)b * 64);
-        seq_partial_64(sb, sPm, R1_pb_ff + (long)b * 64);
+        {
+            const f32x4 pv[2] = {sg, sb};
+            float* const pr[2] = {sPm, sPm + 2048};
+            float* const pd[2] = {R1_pg_ff + (long)b * 64, R1_pb_ff + (long)b * 64};
+            seq_partials_64<2>(pv, pr, pd);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1082,10 +1113,12 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             st4(sT + r * FS + lc, dO);
             st4(sdF + r * FS + lc, dF);
         }
-        seq_partial_64(sga, sPm, R4_pg_a + (long)b * 64);
-        seq_partial_64(sba, sPm, R4_pb_a + (long)b * 64);
-        seq_partial_64(sgf, sPm, R4_pg_f + (long)b * 64);
-        seq_partial_64(sbf, sPm, R4_pb_f + (long)b * 64);
+        {   // (sG's partial tile was consumed by the row pass above: scratch for two of the four vectors)
+            const f32x4 pv[4] = {sga, sba, sgf, sbf};
+            float* const pr[4] = {sPm, sPm + 2048, sG, sG + 2048};
+            float* const pd[4] = {R4_pg_a + (long)b * 64, R4_pb_a + (long)b * 64, R4_pg_f + (long)b * 64, R4_pb_f + (long)b * 64};
+            seq_partials_64<4>(pv, pr, pd);
+        }
     }
     lds_barrier();
 
@@ -1370,10 +1403,16 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
                 sg0 += dx * xh; sb0 += dx;
             }
         }
-        seq_partial_64(sb, sQ, R8_pbeta + (long)b * 64, 2.0f, R8_sqrt_beta);
         if (e_dz) {
-            seq_partial_64(sg0, sQ, KARG(FusedBwdP, e_pg) + (long)b * 64);
-            seq_partial_64(sb0, sQ, KARG(FusedBwdP, e_pb) + (long)b * 64);
+            const f32x4 pv[3] = {sb, sg0, sb0};
+            float* const pr[3] = {sQ, sQ + 2048, sQ + 4096};
+            float* const pd[3] = {R8_pbeta + (long)b * 64, KARG(FusedBwdP, e_pg) + (long)b * 64, KARG(FusedBwdP, e_pb) + (long)b * 64};
+            seq_partials_64<3>(pv, pr, pd, 2.0f, R8_sqrt_beta);
+        } else {
+            const f32x4 pv[1] = {sb};
+            float* const pr[1] = {sQ};
+            float* const pd[1] = {R8_pbeta + (long)b * 64};
+            seq_partials_64<1>(pv, pr, pd, 2.0f, R8_sqrt_beta);
         }
     }
     STAMP(8);
