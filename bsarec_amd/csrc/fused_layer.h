@@ -996,7 +996,36 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R2_w1 = KARG(FusedBwdP, w1);
     const auto R2_w2 = KARG(FusedBwdP, w2);
     // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU (in place over the staged u tile): group g owns blocks 2g, 2g+1
-    {
+    if constexpr (!BF) {
+        // fp32: block 1's MFMA chain (one accumulator, 64 cycles per dependent MFMA) is interleaved with block 0's
+        // gelu' epilogue -- 2 MFMAs, then one output element (~30 VALU + an LDS round trip) -- so the vector work runs in
+        // the issue slots the chain leaves empty instead of after it; both waves of a SIMD otherwise reach their MFMA
+        // bursts and their epilogues together (lockstep) and the matrix pipe idles during every epilogue.
+        const float* sa = sT + arow;
+        const int c0 = (2 * grp) * 64 + col, c1 = c0 + 64;
+        load_wT<BF, 64, 256>(R2_w2, (long)KH * 256 + c1, wB);                          // block 1's weights
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        mma_w<BF, 64>(sa, wA, acc0);
+        load_wT<BF, 64, 64>(R2_w1, (long)(128 * grp + KH) * 64 + col, wA);             // first dH chunk of this group
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 a = ld4(sa + 8 * (r >> 1));
+            const int s0 = 2 * (r & 1);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0], wB.w[r >> 1][s0], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + 1], wB.w[r >> 1][s0 + 1], acc1, 0, 0, 0);
+            const int row = wm * 32 + rho(r) + 4 * half;
+            float* pu = sdU + row * FU + c0;
+            *pu = row < L ? acc0[r] * gelu_grad_f(*pu) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + rho(r) + 4 * half;
+            float* pu = sdU + row * FU + c1;
+            *pu = row < L ? acc1[r] * gelu_grad_f(*pu) : 0.f;
+        }
+    } else {
         const float* sa = sT + arow;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
