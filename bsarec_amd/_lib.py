@@ -42,7 +42,7 @@ class Config(C.Structure):
 
 
 OPTION_FIELDS = ("storage", "no_fused", "no_prune_top", "dw_tiled", "splits", "top_slabs", "separate_embed")
-HIDDEN_ACTS = {"gelu": 0, "relu": 1, "swish": 2}
+HIDDEN_ACTS = {"gelu": 0, "relu": 1, "swish": 2, "tanh": 3, "sigmoid": 4}      # src/model/_modules.py:38-45
 
 # Plan options the HOST gives to plans it creates from now on.  The C ABI has no process-wide state: these are Python
 # defaults (test / bench shims and the environment knobs of INTEGRATION.md), copied into bsarec_config_t per plan.

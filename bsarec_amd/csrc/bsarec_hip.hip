@@ -179,7 +179,7 @@ static int check_cfg(const bsarec_config_t& c) {
     if (c.p_hidden < 0.f || c.p_hidden >= 1.f || c.p_attn < 0.f || c.p_attn >= 1.f) return -8;
     if (c.filter_kind != 0 && c.filter_kind != 1) return -9;
     if (c.filter_kind == 1 && c.cutoff_bins != c.seq_len / 2 + 1) return -9;     // the learnable filter has every rFFT bin
-    if (c.hidden_act != 0) return -14;          // relu / swish: not built yet
+    if (c.hidden_act < 0 || c.hidden_act > 4) return -14;
     if (c.storage < 0 || c.storage > 1) return -15;
     if (c.splits < 0 || c.splits > 1024 || c.top_slabs < 0 || c.top_slabs > 16) return -16;
     return 0;
@@ -187,7 +187,7 @@ static int check_cfg(const bsarec_config_t& c) {
 
 static bool fused_shape_ok(const bsarec_config_t& c) {
     const int dh = c.hidden / c.heads;
-    return !c.no_fused && c.filter_kind == 0 && c.hidden == 64 && c.seq_len <= 64 && c.cutoff_bins <= FUSED_MAX_CB &&
+    return !c.no_fused && c.filter_kind == 0 && c.hidden_act == 0 && c.hidden == 64 && c.seq_len <= 64 && c.cutoff_bins <= FUSED_MAX_CB &&
            (dh == 16 || dh == 32 || dh == 64);
 }
 
@@ -790,7 +790,8 @@ static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* s
             e.gamma = w.ffn_ln_w; e.beta = w.ffn_ln_b; e.eps = c.ln_eps;
             e.Y = p->X[l + 1]; e.xhat = b.xhat_ff; e.rstd = b.rstd_ff;
             e.dsp = nullptr; e.alpha = 0.f; e.oma = 1.f;
-            DISPATCH_BN(d, RET((launch_gemm<64, BN, 2, 2, false, false, XF_GELU, XF_NONE, false>(g, nox, e, nullptr, 1, s, BSAREC_K_FFN2))));
+            XformP xa = nox; xa.act = c.hidden_act;
+            DISPATCH_BN(d, RET((launch_gemm<64, BN, 2, 2, false, false, XF_GELU, XF_NONE, false>(g, xa, e, nullptr, 1, s, BSAREC_K_FFN2))));
         }
     }
     return 0;
@@ -992,7 +993,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
             GemmP g = gemm_defaults(T, 4 * d, d);
             g.lda = d; g.ldb = 4 * d; g.A[0] = p->dT; g.B[0] = w.ffn2_w;
             auto e = epi_linear<false, false, true>(p->dU, 4 * d);
-            e.U = b.u; e.ldu = 4 * d;
+            e.U = b.u; e.ldu = 4 * d; e.act = c.hidden_act;
             RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s, BSAREC_K_DU)));
         }
         {   // dH = dU . W1 + dz
@@ -1111,7 +1112,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                 G.b_gelu[i] = sp[i].gelu;
                 tiles += cdiv(sp[i].M, 64) * G.tiles_n[i];
             }
-            G.tile0[6] = tiles; G.nprob = 6;
+            G.tile0[6] = tiles; G.nprob = 6; G.act = c.hidden_act;
             if (p->fused && p->direct_dw) {
                 // hidden = 64: direct split-K products, one workgroup per (problem, 64x64 tile, slab slice) -- dw_direct.h.
                 // The pruned top block's six (tiny) problems are not launched on their own: they wait in DW and ride in

@@ -108,6 +108,24 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// The reference's other hidden_act choices (src/model/_modules.py:38-59: ACT2FN), selected at run time by the plan's
+// cfg.hidden_act on the generic tiled path (the fused per-sequence kernels implement the default, gelu):
+//   0 gelu (erf form)   1 relu   2 swish = x sigmoid(x)   3 tanh   4 sigmoid
+__device__ __forceinline__ float act_f(float x, int act) {
+    if (act == 0) return gelu_f(x);
+    if (act == 1) return fmaxf(x, 0.f);
+    if (act == 3) return tanhf(x);
+    const float sg = 1.0f / (1.0f + __expf(-x));
+    return act == 2 ? x * sg : sg;
+}
+__device__ __forceinline__ float act_grad_f(float x, int act) {
+    if (act == 0) return gelu_grad_f(x);
+    if (act == 1) return x > 0.f ? 1.0f : 0.f;
+    if (act == 3) { const float t = tanhf(x); return 1.0f - t * t; }
+    const float sg = 1.0f / (1.0f + __expf(-x));
+    return act == 2 ? sg * (1.0f + x * (1.0f - sg)) : sg * (1.0f - sg);
+}
+
 // ---------------------------------------------------------------------------------------------
 // all-lanes reductions inside a group of W consecutive lanes (W = 16, 32 or 64).  The 16-lane part is four
 // DPP steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) -- no LDS traffic, unlike __shfl_xor which

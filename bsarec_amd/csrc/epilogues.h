@@ -13,6 +13,7 @@ struct EpiLinear {
     const float* bias[3];
     const float* R; long ldr;
     const float* U; long ldu;
+    int act;                           // GGRAD: which hidden_act's derivative (0 = gelu)
 
     template <int BM, int BN>
     __device__ __forceinline__ void run(const float* Cs, const TileCtx& c) const {
@@ -26,7 +27,7 @@ struct EpiLinear {
             if (BIAS) v += ld4(bias[c.prob] + n);
             if (GGRAD) {
                 const f32x4 u = ld4(U + (long)m * ldu + n);
-                v.x *= gelu_grad_f(u.x); v.y *= gelu_grad_f(u.y); v.z *= gelu_grad_f(u.z); v.w *= gelu_grad_f(u.w);
+                v.x *= act_grad_f(u.x, act); v.y *= act_grad_f(u.y, act); v.z *= act_grad_f(u.z, act); v.w *= act_grad_f(u.w, act);
             }
             if (ADD) v += ld4(R + (long)m * ldr + n);
             st4(out + (long)m * ldc + n, v);
@@ -163,8 +164,9 @@ struct GroupedTN {
     float* bgrad[GROUP_MAX];
     int tile0[GROUP_MAX + 1];
     int tiles_n[GROUP_MAX];
-    int b_gelu[GROUP_MAX];          // apply erf-GELU to the B operand while loading (dW2 = dT^T . gelu(U))
+    int b_gelu[GROUP_MAX];          // apply the hidden_act to the B operand while loading (dW2 = dT^T . act(U))
     int nprob;
+    int act;                        // which hidden_act (0 = gelu)
 };
 
 __global__ void __launch_bounds__(GEMM_THREADS)
@@ -175,7 +177,7 @@ gemm_grouped_tn_kernel(const GroupedTN G) {
     const int local = blockIdx.x - G.tile0[p];
     const int bx = local / G.tiles_n[p], by = local % G.tiles_n[p];
     XformP X;
-    X.L = 0; X.Lp = 0; X.drop.thresh = 0; X.drop.scale = 1.f; X.drop.rng = nullptr; X.drop.site = 0;
+    X.L = 0; X.Lp = 0; X.drop.thresh = 0; X.drop.scale = 1.f; X.drop.rng = nullptr; X.drop.site = 0; X.act = G.act;
     if (G.b_gelu[p])
         gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_GELU, true>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
     else

@@ -40,6 +40,7 @@ struct GemmP {
 struct XformP {           // operand transform applied while loading
     DropP drop;           // XF_DROP: attention-probability dropout regenerated on load
     int L, Lp;            // XF_DROP: element index = ((zb*L + q)*Lp + key)
+    int act;              // XF_GELU: which hidden_act (common.h act_f; 0 = gelu)
 };
 
 struct TileCtx {          // what an epilogue needs to know about its tile
@@ -60,7 +61,7 @@ struct TileLoader {
 
     __device__ __forceinline__ f32x4 xform(f32x4 x, int q, int key0, bool valid, const XformP& X, int zb) const {
         if (XF == XF_GELU) {
-            x.x = gelu_f(x.x); x.y = gelu_f(x.y); x.z = gelu_f(x.z); x.w = gelu_f(x.w);
+            x.x = act_f(x.x, X.act); x.y = act_f(x.y, X.act); x.z = act_f(x.z, X.act); x.w = act_f(x.w, X.act);
         } else if (XF == XF_DROP) {
             if (valid) {
                 const uint64_t e = ((uint64_t)zb * X.L + q) * X.Lp + key0;

@@ -48,7 +48,8 @@ typedef struct {
                          * 1: FMLPRec's learnable complex filter irfft(rfft(x) * W) (src/model/fmlprec.py:96-113): the
                          *    layer's filter_cw tensor is used, cutoff_bins must be L/2 + 1, generic kernels only */
     /* ---- per-plan options; 0 selects the default everywhere, so a zero-filled tail is a valid configuration ---- */
-    int hidden_act;     /* FeedForward activation (src/model/_modules.py:38-45): 0 gelu (erf form, the default), 1 relu, 2 swish */
+    int hidden_act;     /* FeedForward activation (src/model/_modules.py:38-59, ACT2FN): 0 gelu (erf form, the default), 1 relu,
+                         * 2 swish, 3 tanh, 4 sigmoid.  Non-default activations run on the generic tiled kernels */
     int storage;        /* 0: fp32 everywhere (the reference's arithmetic); 1: bf16 storage of the saved activations and of a
                          *    bf16 shadow of the Linear weights, bf16 MFMA with fp32 accumulation, fp32 master weights, fp32
                          *    LayerNorm / softmax / loss / Adam (config C2; fused shape hidden = 64, L <= 64 only) */

@@ -49,6 +49,7 @@ class Config:
     attention_probs_dropout_prob: float = 0.5
     initializer_range: float = 0.02
     eps: float = 1e-12
+    hidden_act: str = "gelu"          # src/model/_modules.py:38-45 (ACT2FN): gelu | relu | swish | tanh | sigmoid
 
     @property
     def head_size(self) -> int:
@@ -208,6 +209,24 @@ def gelu_grad(x):
     return cdf + x * pdf
 
 
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def hidden_act_fn(name: str):
+    """FeedForward.get_hidden_act (src/model/_modules.py:38-59)."""
+    return {"gelu": gelu, "relu": lambda x: np.maximum(x, 0), "swish": lambda x: x * _sigmoid(x), "tanh": np.tanh,
+            "sigmoid": _sigmoid}[name]
+
+
+def hidden_act_grad(name: str):
+    def swish_grad(x):
+        sg = _sigmoid(x)
+        return sg * (1 + x * (1 - sg))
+    return {"gelu": gelu_grad, "relu": lambda x: (x > 0).astype(x.dtype), "swish": swish_grad,
+            "tanh": lambda x: 1 - np.tanh(x) ** 2, "sigmoid": lambda x: _sigmoid(x) * (1 - _sigmoid(x))}[name]
+
+
 def attention_mask(ids):
     """Additive causal+padding mask in {0, -10000}, f32[B,1,L,L]
     (src/model/_abstract_model.py:53-69)."""
@@ -364,7 +383,7 @@ def forward(params: Dict[str, np.ndarray], cfg: Config, ids: np.ndarray,
         # FeedForward                                                 _modules.py:61-69
         fp = p + "feed_forward."
         u = hmix @ P[fp + "dense_1.weight"].T + P[fp + "dense_1.bias"]
-        g = gelu(u)
+        g = hidden_act_fn(cfg.hidden_act)(u)
         y2 = g @ P[fp + "dense_2.weight"].T + P[fp + "dense_2.bias"]
         y2d, lc["keep_ff"] = _drop(y2, ph, drop, 4 + 4 * l)
         y, lc["ln_ff"] = layer_norm_fwd(y2d + hmix, P[fp + "LayerNorm.weight"], P[fp + "LayerNorm.bias"], cfg.eps)
@@ -479,7 +498,7 @@ def loss_and_grads(params, cfg: Config, ids, answers, drop: Optional[DropoutSpec
         dy2 = undrop(dz, lc["keep_ff"], sc_h)
         G[fp + "dense_2.weight"] = dy2.reshape(-1, d).T @ lc["g"].reshape(-1, 4 * d)
         G[fp + "dense_2.bias"] = dy2.reshape(-1, d).sum(0)
-        du = (dy2 @ P[fp + "dense_2.weight"]) * gelu_grad(lc["u"])
+        du = (dy2 @ P[fp + "dense_2.weight"]) * hidden_act_grad(cfg.hidden_act)(lc["u"])
         G[fp + "dense_1.weight"] = du.reshape(-1, 4 * d).T @ lc["hmix"].reshape(-1, d)
         G[fp + "dense_1.bias"] = du.reshape(-1, 4 * d).sum(0)
         dh_ = du @ P[fp + "dense_1.weight"] + dz
