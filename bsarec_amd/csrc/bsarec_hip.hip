@@ -107,6 +107,7 @@ static EpiLinear<BIAS, ADD, GGRAD> epi_linear(float* C, long ldc) {
 // ---------------------------------------------------------------------------------------------
 struct LayerBufs {
     float *dsp, *xhat_f, *rstd_f, *q, *k, *v, *probs, *ctx, *xhat_a, *rstd_a, *hmix, *u, *xhat_ff, *rstd_ff;
+    float* gp;       // fused path: gelu'(pre-activation) [T, 4d]; there `u` holds gelu(pre-activation) (one-row top block: u itself)
 };
 
 struct bsarec_plan {
@@ -240,6 +241,7 @@ static void carve(bsarec_plan& p, char* base, size_t* total) {
         b.probs = cv.take<float>(B * h * L * p.Lp); b.ctx = cv.take<float>(Td);
         b.xhat_a = cv.take<float>(Td); b.rstd_a = cv.take<float>(T); b.hmix = cv.take<float>(Td);
         b.u = cv.take<float>(4 * Td); b.xhat_ff = cv.take<float>(Td); b.rstd_ff = cv.take<float>(T);
+        b.gp = p.fused ? cv.take<float>(4 * Td) : nullptr;
     }
     p.logits = cv.take<float>(B * p.Vp); p.dlogits = cv.take<float>(B * p.Vp);
     p.loss_rows = cv.take<float>(B); p.loss = cv.take<float>(4);
@@ -536,6 +538,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
     F.tw = p.twiddle; F.ids32 = p.ids32;
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs; F.ctx = b.ctx;
     F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.hmix = b.hmix; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
+    F.gp = b.gp;
     F.dsp = nullptr;          // FrequencyLayer output stays in LDS on the fused path (BSAREC_BUF_DSP is generic-path only)
     if (l == 0 && gp) {       // the embedding front-end rides in the bottom block's phase 0
         F.e_E = p.P.item_emb; F.e_pos = p.P.pos_emb; F.e_g = p.P.ln_w; F.e_b = p.P.ln_b; F.e_ids = ids; F.e_gp = *gp;
@@ -573,7 +576,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.wq = wm.query_w; F.wk = wm.key_w; F.wv = wm.value_w; F.wo = wm.dense_w;
     F.a_g = w.attn_ln_w; F.w1 = wm.ffn1_w; F.w2 = wm.ffn2_w; F.ff_g = w.ffn_ln_w; F.tw = p.twiddle;
     F.xhat_f = b.xhat_f; F.rstd_f = b.rstd_f; F.q = b.q; F.k = b.k; F.v = b.v; F.probs = b.probs;
-    F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.u; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
+    F.xhat_a = b.xhat_a; F.rstd_a = b.rstd_a; F.u = b.gp; F.xhat_ff = b.xhat_ff; F.rstd_ff = b.rstd_ff;
     if (top) { F.dh_slabs = p.dlast_slab; F.dh_nsplit = p.loss_kind == 1 ? 1 : p.vsplit; F.dh_stride = (long)c.batch * d; }
     if (l == 0) {       // the embedding front-end's backward (Drop + LayerNorm) rides in the bottom block's epilogue
         F.e_dz = p.dz; F.e_xhat = p.xhat0; F.e_rstd = p.rstd0; F.e_g = p.P.ln_w;
@@ -1072,7 +1075,9 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
             const Spec sp[6] = {
                 {p->dq, d, X, d, d, d, sm.wq, sm.bq, 0},        {p->dk, d, X, d, d, d, sm.wk, sm.bk, 0},
                 {p->dv, d, X, d, d, d, sm.wv, sm.bv, 0},        {p->dO, d, b.ctx, d, d, d, sm.wo, sm.bo, 0},
-                {p->dU, 4 * d, b.hmix, d, 4 * d, d, sm.w1, sm.b1, 0}, {p->dT, d, b.u, 4 * d, d, 4 * d, sm.w2, sm.b2, 1}};
+                {p->dU, 4 * d, b.hmix, d, 4 * d, d, sm.w1, sm.b1, 0},
+                // dW2 = dT2^T . act(u): the full fused forward already saved gelu(u) in `u`; elsewhere apply it while loading
+                {p->dT, d, b.u, 4 * d, d, 4 * d, sm.w2, sm.b2, (p->fused && !top_pruned) ? 0 : 1}};
             int tiles = 0;
             // Top block: only position L-1 of each sequence carries an upstream gradient (bsarec.py:32), so dq, dO, dU
             // and dT2 are zero on every other row: their four products reduce over the B last positions only

@@ -26,6 +26,8 @@ struct FusedFwdP {
     const float *sqrt_beta, *f_g, *f_b, *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *a_g, *a_b, *w1, *b1, *w2, *b2, *ff_g, *ff_b;
     const float* tw; const int* ids32;
     float *xhat_f, *rstd_f, *q, *k, *v, *probs, *ctx, *xhat_a, *rstd_a, *hmix, *u, *xhat_ff, *rstd_ff, *dsp;
+    float* gp;              // [B, L, 4d] gelu'(pre-activation); `u` receives gelu(pre-activation) -- what the backward's two
+                            // consumers need (dU = (dT2 . W2) * gelu'; dW2 = dT2^T . gelu), neither has to evaluate erf again
     int L, Lp, cb, heads;
     float alpha, oma, eps;
     DropP drop_f, drop_p, drop_o, drop_ff;
@@ -747,16 +749,19 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     STAMP(6);
     const auto R6_w2 = KARG(FusedFwdP, w2);
     const auto R6_u = KARG(FusedFwdP, u);
-    // ---- phase 6: u write-out + erf-GELU pass, dense_2 (K split: group g owns inner columns [128g, 128g+128)) + dropout + residual + LN
+    const auto R6_gp = KARG(FusedFwdP, gp);
+    // ---- phase 6: erf-GELU pass (+ write-out for the backward), dense_2 (K split: group g owns inner columns [128g, 128g+128)) + dropout + residual + LN
     {
-        // pre-activation u -> global as whole rows (the backward needs it for gelu'); gelu(u) replaces it in LDS,
-        // once per element (applying it in dense_2's operand loads would evaluate it once per column tile)
+        // gelu(u) replaces the pre-activation in LDS, once per element (applying it in dense_2's operand loads would
+        // evaluate it once per column tile); gelu(u) and gelu'(u) -> global as whole rows for the backward
         for (int idx = tid; idx < 64 * 64; idx += 512) {
             const int r = idx >> 6, c4 = (idx & 63) << 2;
-            f32x4 v = ld4(sU + r * FU + c4);
-            if (r < L) ast4<BF>(R6_u, (tok0 + r) * 256 + c4, v);
-            v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
-            st4(sU + r * FU + c4, v);
+            const f32x4 v = ld4(sU + r * FU + c4);
+            float g0, g1, g2, g3, p0, p1, p2, p3;
+            gelu_both(v.x, g0, p0); gelu_both(v.y, g1, p1); gelu_both(v.z, g2, p2); gelu_both(v.w, g3, p3);
+            const f32x4 g = {g0, g1, g2, g3}, gp = {p0, p1, p2, p3};
+            if (r < L) { ast4<BF>(R6_u, (tok0 + r) * 256 + c4, g); ast4<BF>(R6_gp, (tok0 + r) * 256 + c4, gp); }
+            st4(sU + r * FU + c4, g);
         }
         lds_barrier();
         f32x16 acc;
@@ -805,7 +810,7 @@ struct FusedBwdP {
     const float* dY; float* dX; const float* X;
     const float *sqrt_beta, *f_g, *wq, *wk, *wv, *wo, *a_g, *w1, *w2, *ff_g;
     const float* tw;
-    const float *xhat_f, *rstd_f, *q, *k, *v, *probs, *xhat_a, *rstd_a, *u, *xhat_ff, *rstd_ff;
+    const float *xhat_f, *rstd_f, *q, *k, *v, *probs, *xhat_a, *rstd_a, *u, *xhat_ff, *rstd_ff;    // u: gelu'(pre-activation), as the forward saved it
     const float* dh_slabs; int dh_nsplit; long dh_stride;   // top layer: dY = 0 except row L-1 = sum of split-K slabs [s][B][64]
     float *dT, *dU, *dO, *dq, *dk, *dv;                     // operands of the weight-gradient products
     float *pg_ff, *pb_ff, *pg_a, *pb_a, *pg_f, *pb_f, *pbeta;   // [B][64] partials
@@ -946,7 +951,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         }
     }
     f32x4 uv[8];
-    {   // pre-activation tile u [64][256] -> registers now, LDS after stage A1's row pass; consumed by stage A2
+    {   // gelu'(pre-activation) tile [64][256] (saved by the forward) -> registers now, LDS after stage A1's row pass; consumed by stage A2
         const float* gu = KARG(FusedBwdP, u);
         // branch-free: a predicated load becomes a branch and the loop then waits for every load before issuing the next
         // (8 serial round trips); rows past L re-read row L-1 (a valid address) and are zeroed on the way to LDS
@@ -1017,13 +1022,13 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + 1], wB.w[r >> 1][s0 + 1], acc1, 0, 0, 0);
             const int row = wm * 32 + rho(r) + 4 * half;
             float* pu = sdU + row * FU + c0;
-            *pu = row < L ? acc0[r] * gelu_grad_f(*pu) : 0.f;
+            *pu = row < L ? acc0[r] * *pu : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + rho(r) + 4 * half;
             float* pu = sdU + row * FU + c1;
-            *pu = row < L ? acc1[r] * gelu_grad_f(*pu) : 0.f;
+            *pu = row < L ? acc1[r] * *pu : 0.f;
         }
     } else {
         const float* sa = sT + arow;
@@ -1042,7 +1047,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
                 float* pu = sdU + row * FU + c256;
-                *pu = row < L ? acc[r] * gelu_grad_f(*pu) : 0.f;
+                *pu = row < L ? acc[r] * *pu : 0.f;
             }
         }
     }
