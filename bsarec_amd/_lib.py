@@ -160,6 +160,24 @@ COMM_EXPORTS = {
     "bsarec_comm_barrier": (C.c_int, [C.POINTER(Comm), C.c_void_p]),
 }
 
+# include/bsarec_shard.h
+PTRS8 = C.c_void_p * 8
+SHARD_EXPORTS = {
+    "bsarec_shard_gather_rows": (C.c_int, [C.c_void_p, C.c_long, C.POINTER(PTRS8), C.c_int, C.c_long, C.c_long, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_shard_logits": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long,
+                                      C.c_void_p]),
+    "bsarec_shard_ce_stats": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p,
+                                        C.c_void_p]),
+    "bsarec_shard_ce_grad": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_shard_head_bwd_scratch_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),
+    "bsarec_shard_head_bwd": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_shard_scatter_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.POINTER(PTRS8), C.c_long, C.c_long, C.c_long,
+                                            C.c_int, C.c_void_p, C.c_void_p]),
+}
+
 _lib = None
 
 
@@ -185,7 +203,7 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -m bsarec_amd.build` (hipcc, gfx950). "
             "bsarec_amd has no fallback path.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in list(EXPORTS.items()) + list(COMM_EXPORTS.items()):
+    for name, (res, args) in list(EXPORTS.items()) + list(COMM_EXPORTS.items()) + list(SHARD_EXPORTS.items()):
         fn = getattr(lib, name)       # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args

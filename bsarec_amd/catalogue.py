@@ -1,0 +1,183 @@
+"""Catalogue-sharded BSARec training step (the C5 variant; include/bsarec_shard.h).
+
+New functionality -- the reference is single-device (src/main.py:19).  At V = 10 M items and d = 256 a replicated item
+table costs 41 GB per GPU (weights, gradient, Adam moments) and a dense 10.24 GB gradient all-reduce per step; here rank
+r OWNS rows [r*rows_per, (r+1)*rows_per) of ``item_embeddings.weight`` -- their gradient and their Adam moments never
+leave the GPU -- and the encoder (everything else, ~1.6 M parameters) stays a data-parallel replica.
+
+What the reference does in `calculate_loss` (src/model/bsarec.py:30-37) maps to one step like this (per rank, B local
+sequences, Bg = W*B):
+
+  lookup           token rows are READ out of the owners' shards over xGMI (IPC-mapped hipMalloc memory) into a staging
+                   table [B*L + 1, d]; the ordinary encoder plan runs over it with item_size = B*L + 1
+  all-gather       h_last [Bg, d], answers [Bg], token ids [W, B*L]
+  head             partial logits of ALL Bg sequences against the owned rows; per-row (max, sum exp, target logit)
+  all-gather       the statistics [W, 3, Bg] -> lse, loss (identical on every rank), d loss / d logits of the owned slice
+  head backward    dE of the owned rows: complete and local; partial d h_last -> all-reduce [Bg, d], keep the own rows
+  encoder backward bsarec_backward_seq; the staging table's gradient holds one row per token
+  barrier          (bsarec_comm_barrier) every rank's gradients are complete
+  lookup gradient  owners PULL the token rows of their items out of every rank's staging gradient
+  Adam             encoder: the fused Adam sums every rank's gradient arena in rank order (replicas stay bit-identical);
+                   shard: local dE, local moments
+
+The loss is the mean over the global batch: d loss / d logits carries 1 / Bg, so every gradient is already the
+global-batch one and the encoder's Adam takes the plain SUM over ranks (grad_scale = 1).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .dp import PeerExchange, _as_tensor
+from .model import BSARecModel
+
+
+class ShardedCatalogue:
+    """One rank of the catalogue-sharded step.  ``args`` are the reference's (global ``item_size``); ``batch`` is the
+    per-rank batch size (fixed: the staging table and the encoder plan are sized by it)."""
+
+    def __init__(self, args, batch: int, group, device):
+        import torch.distributed as dist
+        self.args, self.group, self.device, self.B = args, group, torch.device(device), int(batch)
+        self.rank, self.W = dist.get_rank(group), dist.get_world_size(group)
+        if self.W > 8:
+            raise ValueError("catalogue sharding runs inside one xGMI node (<= 8 ranks)")
+        if getattr(args, "storage", None) == "bf16":
+            raise ValueError("catalogue sharding is fp32 only")
+        V, d, Lq = int(args.item_size), int(args.hidden_size), int(args.max_seq_length)
+        self.V, self.d, self.Lq = V, d, Lq
+        self.rows_per = (V + self.W - 1) // self.W
+        self.lo = self.rank * self.rows_per
+        self.Vs = max(0, min(self.rows_per, V - self.lo))
+        self.n = self.B * Lq
+        self.Bg = self.W * self.B
+        self.lib = L.load()
+        # encoder replica over the staging table
+        enc_args = copy.copy(args)
+        enc_args.item_size = self.n + 1
+        enc_args.plan_options = dict(getattr(args, "plan_options", None) or {})
+        self.encoder = BSARecModel(enc_args).to(self.device)
+        off, self.stage_n, _ = self.encoder._slices["item_embeddings.weight"]
+        assert off == 0 and self.stage_n == (self.n + 1) * d
+        dist.broadcast(self.encoder._arena, src=dist.get_global_rank(group, 0), group=group)       # identical replicas
+        self.encoder.set_seed(int(getattr(args, "seed", 42)), self.rank)
+        # peer-to-peer plumbing: gradient arenas + the table shards in IPC-exported memory
+        px = PeerExchange.create(self.encoder._numel, group, self.device)
+        if px is None:
+            raise RuntimeError("catalogue sharding needs the peer-to-peer mappings (hipIpc) between the ranks of the node")
+        self.px = px
+        self.encoder.use_grad_arenas(px.arenas)
+        e_ptr, self.shard_ptrs = px.share(max(self.rows_per, 1) * d * 4)
+        self.E = _as_tensor(e_ptr, self.rows_per * d, torch.float32, self.device).view(self.rows_per, d)
+        gen = torch.Generator(device="cpu").manual_seed(int(getattr(args, "seed", 42)) * 1000003 + self.rank)
+        self.E.copy_(torch.empty(self.rows_per, d).normal_(0.0, float(args.initializer_range), generator=gen))
+        self.dE = torch.zeros_like(self.E)
+        self.m, self.v = torch.zeros_like(self.E), torch.zeros_like(self.E)
+        self.encoder.configure_adam(lr=float(getattr(args, "lr", 1e-3)),
+                                    betas=(float(getattr(args, "adam_beta1", 0.9)), float(getattr(args, "adam_beta2", 0.999))),
+                                    weight_decay=float(getattr(args, "weight_decay", 0.0)))
+        # head buffers
+        self.ld = (max(self.Vs, 1) + 3) // 4 * 4
+        self.logits = torch.zeros(self.Bg, self.ld, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(3, self.Bg, dtype=torch.float32, device=self.device)
+        self.stats_all = torch.zeros(self.W, 3, self.Bg, dtype=torch.float32, device=self.device)
+        self.h_all = torch.zeros(self.Bg, d, dtype=torch.float32, device=self.device)
+        self.ans_all = torch.zeros(self.Bg, dtype=torch.int64, device=self.device)
+        self.ids_all = torch.zeros(self.W, self.n, dtype=torch.int64, device=self.device)
+        self.local_ids = torch.zeros(self.B, Lq, dtype=torch.int64, device=self.device)
+        self.dh = torch.zeros(self.Bg, d, dtype=torch.float32, device=self.device)
+        self.scratch = torch.zeros(max(1, self.lib.bsarec_shard_head_bwd_scratch_floats(self.Bg, self.Vs, d)),
+                                   dtype=torch.float32, device=self.device)
+        self.d_out = torch.zeros(self.B, Lq, d, dtype=torch.float32, device=self.device)
+        self.loss_rows = torch.zeros(self.Bg, dtype=torch.float32, device=self.device)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._shards8 = L.PTRS8(*([int(p) for p in self.shard_ptrs] + [None] * (8 - self.W)))
+        self._grads8 = L.PTRS8(*([int(p) for p in px.grad_srcs(0)] + [None] * (8 - self.W)))
+        dist.barrier(group=group)
+
+    # ---- weights ---------------------------------------------------------------------------------------------------
+    def load_full_state_dict(self, sd):
+        """Reference-keyed state dict with the FULL item table: this rank keeps its rows and the encoder parameters."""
+        full = sd["item_embeddings.weight"].to(device=self.device, dtype=torch.float32)
+        assert tuple(full.shape) == (self.V, self.d)
+        self.E.zero_()
+        if self.Vs:
+            self.E[:self.Vs].copy_(full[self.lo:self.lo + self.Vs])
+        own = self.encoder.state_dict()
+        for k in own:
+            if k != "item_embeddings.weight":
+                own[k].copy_(sd[k].to(device=self.device, dtype=torch.float32))
+        torch.cuda.synchronize(self.device)
+        torch.distributed.barrier(group=self.group)
+
+    def full_state_dict(self):
+        """The reference's state dict (full item table gathered from the owners; checkpoints of small catalogues, tests)."""
+        parts = [torch.empty_like(self.E) for _ in range(self.W)]
+        torch.distributed.all_gather(parts, self.E.contiguous(), group=self.group)
+        sd = {k: v.detach().clone() for k, v in self.encoder.state_dict().items()}
+        sd["item_embeddings.weight"] = torch.cat(parts, 0)[:self.V].clone()
+        return sd
+
+    # ---- one training step -----------------------------------------------------------------------------------------
+    def _adam(self, params, grads, m, v, n, srcs=None):
+        a = self.encoder._adam
+        s = L.Adam(params, grads, m, v, n, a["lr"], a["b1"], a["b2"], a["eps"], a["wd"], 1.0, None, 0)
+        if srcs:
+            s.n_grad_srcs = len(srcs)
+            for i, p in enumerate(srcs):
+                s.grad_srcs[i] = p
+        return s
+
+    def train_step(self, input_ids, answers) -> torch.Tensor:
+        """input_ids [B, L], answers [B]: this rank's slice of the global batch.  Returns the device loss scalar (mean
+        over the GLOBAL batch, the same value on every rank)."""
+        import torch.distributed as dist
+        lib, enc, g = self.lib, self.encoder, self.group
+        B, Lq, d, W, Bg, n = self.B, self.Lq, self.d, self.W, self.Bg, self.n
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        ans = answers.to(device=self.device, dtype=torch.int64).contiguous()
+        assert tuple(ids.shape) == (B, Lq) and tuple(ans.shape) == (B,)
+        st = enc._stream()
+        # peers finished the previous step: their shards are current, nobody reads my old staging gradient any more
+        self.px.barrier(st)
+        L.check(lib.bsarec_shard_gather_rows(ids.data_ptr(), n, C.byref(self._shards8), W, self.rows_per, self.V, d,
+                                             enc._arena.data_ptr(), self.local_ids.data_ptr(), st), "bsarec_shard_gather_rows")
+        enc.train()
+        plan = enc._run_forward(self.local_ids, train=True, new_step=True)
+        h_last = plan.view(L.BUF_LAYER_OUT, self.args.num_hidden_layers, (B, Lq, d))[:, Lq - 1, :].float().contiguous()
+        dist.all_gather(list(self.h_all.view(W, B, d).unbind(0)), h_last, group=g)
+        dist.all_gather(list(self.ans_all.view(W, B).unbind(0)), ans, group=g)
+        dist.all_gather(list(self.ids_all.unbind(0)), ids.view(-1), group=g)
+        L.check(lib.bsarec_shard_logits(self.h_all.data_ptr(), d, Bg, self.E.data_ptr(), self.Vs, d, self.logits.data_ptr(),
+                                        self.ld, st), "bsarec_shard_logits")
+        L.check(lib.bsarec_shard_ce_stats(self.logits.data_ptr(), self.ld, Bg, self.Vs, self.ans_all.data_ptr(), self.lo, self.V,
+                                          self.stats.data_ptr(), st), "bsarec_shard_ce_stats")
+        dist.all_gather(list(self.stats_all.unbind(0)), self.stats, group=g)
+        L.check(lib.bsarec_shard_ce_grad(self.logits.data_ptr(), self.ld, Bg, self.Vs, self.ans_all.data_ptr(), self.lo, self.V,
+                                         self.stats_all.data_ptr(), W, self.loss_rows.data_ptr(), self.loss.data_ptr(), st),
+                "bsarec_shard_ce_grad")
+        L.check(lib.bsarec_shard_head_bwd(self.logits.data_ptr(), self.ld, Bg, self.Vs, self.h_all.data_ptr(), d,
+                                          self.E.data_ptr(), d, self.dE.data_ptr(), self.dh.data_ptr(), self.scratch.data_ptr(), st),
+                "bsarec_shard_head_bwd")
+        dist.all_reduce(self.dh, op=dist.ReduceOp.SUM, group=g)
+        self.d_out[:, Lq - 1, :] = self.dh[self.rank * B:(self.rank + 1) * B]
+        L.check(lib.bsarec_backward_seq(plan.handle, self.d_out.data_ptr(), st), "bsarec_backward_seq")
+        self.px.barrier(st)                 # every rank's gradient arena (staging rows + encoder) is complete
+        L.check(lib.bsarec_shard_scatter_rows(self.ids_all.data_ptr(), n, W, C.byref(self._grads8), self.lo, self.Vs, self.V, d,
+                                              self.dE.data_ptr(), st), "bsarec_shard_scatter_rows")
+        sn, a = self.stage_n, enc._adam
+        ad = self._adam(enc._arena.data_ptr() + 4 * sn, enc._garena.data_ptr() + 4 * sn, a["m"].data_ptr() + 4 * sn,
+                        a["v"].data_ptr() + 4 * sn, enc._numel - sn, [p + 4 * sn for p in self.px.grad_srcs(0)])
+        L.check(lib.bsarec_adam_step(C.byref(ad), enc._state.data_ptr(), st), "bsarec_adam_step")
+        if self.Vs:
+            ae = self._adam(self.E.data_ptr(), self.dE.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.Vs * d)
+            L.check(lib.bsarec_adam_apply(C.byref(ae), enc._state.data_ptr(), st), "bsarec_adam_apply")
+        return self.loss[0]
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        torch.distributed.barrier(group=self.group)
+        self.px.close()

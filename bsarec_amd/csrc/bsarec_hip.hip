@@ -1,11 +1,13 @@
 // MI355X (gfx950) BSARec training hot path: launch plan + C ABI.  See include/bsarec_hip.h.
 #include "../../include/bsarec_hip.h"
+#include "../../include/bsarec_shard.h"
 #include "epilogues.h"
 #include "kernels.h"
 #include "fused_layer.h"
 #include "dw_direct.h"
 #include "fused_top.h"
 #include "comm.h"
+#include "catalogue_shard.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -1410,4 +1412,117 @@ extern "C" int bsarec_profile_event_overhead(void* stream, int reps, double* ms_
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     if (ms_avg) *ms_avg = reps > 0 ? tot / reps : 0.0;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// catalogue-sharded head (include/bsarec_shard.h, catalogue_shard.h)
+// ---------------------------------------------------------------------------------------------
+static int shard_ptrs(ShardPtrs& S, const float* const* p, int world) {
+    if (!p || world < 1 || world > 8) return -10;
+    memset(&S, 0, sizeof(S));
+    for (int r = 0; r < world; ++r) { if (!p[r]) return -10; S.p[r] = p[r]; }
+    return 0;
+}
+
+extern "C" int bsarec_shard_gather_rows(const int64_t* ids, long n, const float* const* shards, int world, long rows_per,
+                                        long V, int d, float* stage, int64_t* local_ids, void* stream) {
+    if (!ids || !stage || !local_ids || n < 1 || rows_per < 1 || V < 1 || d < 4 || (d & 3)) return -10;
+    if ((V + rows_per - 1) / rows_per > world) return -11;
+    ShardPtrs S;
+    RET(shard_ptrs(S, shards, world));
+    const int d4 = d / 4;
+    LAUNCH(shard_gather_rows_kernel, dim3(cdiv((n + 1) * d4, 256)), dim3(256), 0, (hipStream_t)stream, ids, n, S, rows_per, V, d4,
+           stage, local_ids);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_shard_logits(const float* h, long ldh, int Bg, const float* E, int Vs, int d, float* logits, long ld,
+                                   void* stream) {
+    if (!h || !logits || Bg < 1 || Vs < 0 || d < 4 || (d & 3) || ld < Vs || (ld & 3) || ldh < d) return -10;
+    if (Vs == 0) return 0;
+    if (!E) return -10;
+    GemmP g = gemm_defaults(Bg, (int)ld, d);
+    g.Nb = Vs; g.lda = ldh; g.ldb = d;
+    g.A[0] = h; g.B[0] = E;
+    auto e = epi_linear<false, false, false>(logits, ld);
+    return launch_gemm<64, 64, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, no_xform(), e, nullptr, 1, (hipStream_t)stream);
+}
+
+extern "C" int bsarec_shard_ce_stats(const float* logits, long ld, int Bg, int Vs, const int64_t* answers, long lo, long V,
+                                     float* stats, void* stream) {
+    if (!logits || !answers || !stats || Bg < 1 || Vs < 0 || ld < Vs || (ld & 3)) return -10;
+    LAUNCH(shard_ce_stats_kernel, dim3(Bg), dim3(ROW_THREADS), 0, (hipStream_t)stream, logits, ld, Vs, answers, lo, V, stats, Bg);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_shard_ce_grad(float* logits, long ld, int Bg, int Vs, const int64_t* answers, long lo, long V,
+                                    const float* stats_all, int world, float* loss_rows, float* loss, void* stream) {
+    if (!logits || !answers || !stats_all || !loss_rows || Bg < 1 || Vs < 0 || ld < Vs || (ld & 3) || world < 1 || world > 8)
+        return -10;
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(shard_ce_grad_kernel, dim3(Bg), dim3(ROW_THREADS), 0, s, logits, ld, Vs, answers, lo, V, stats_all, world, Bg,
+           1.0f / (float)Bg, loss_rows);
+    HIPCHK(hipGetLastError());
+    if (loss) LAUNCH(loss_mean_kernel, dim3(1), dim3(ROW_THREADS), 0, s, loss_rows, Bg, loss);
+    return (int)hipGetLastError();
+}
+
+// split-K over the owned rows for d h_last: enough slices to fill the chip at small Bg, chunks of >= 4096 rows
+static void shard_split(int Bg, int Vs, int d, int* nsplit, int* kchunk) {
+    const long tiles = (long)cdiv(Bg, 64) * cdiv(d, 64);
+    long want = (1024 + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    if (want > 64) want = 64;
+    long ch = rup(cdiv(Vs > 0 ? Vs : 1, want), GEMM_BK);
+    if (ch < 256) ch = 256;
+    *kchunk = (int)ch;
+    *nsplit = cdiv(Vs > 0 ? Vs : 1, ch);
+}
+
+extern "C" long bsarec_shard_head_bwd_scratch_floats(int Bg, int Vs, int d) {
+    if (Bg < 1 || Vs < 0 || d < 4) return -10;
+    int ns, kc;
+    shard_split(Bg, Vs, d, &ns, &kc);
+    return (long)ns * Bg * d;
+}
+
+extern "C" int bsarec_shard_head_bwd(const float* dlogits, long ld, int Bg, int Vs, const float* h, long ldh, const float* E,
+                                     int d, float* dE, float* dh, float* scratch, void* stream) {
+    if (!dlogits || !h || !dh || !scratch || Bg < 1 || Vs < 0 || d < 4 || (d & 3) || ld < Vs || (ld & 3) || ldh < d) return -10;
+    hipStream_t s = (hipStream_t)stream;
+    if (Vs == 0) { if (!g_dry) HIPCHK(hipMemsetAsync(dh, 0, (size_t)Bg * d * sizeof(float), s)); return 0; }
+    if (!E || !dE) return -10;
+    const XformP nox = no_xform();
+    {       // dE[v, :] = sum_b dlogits[b, v] h[b, :]
+        GemmP g = gemm_defaults(Vs, d, Bg);
+        g.lda = ld; g.ldb = ldh; g.A[0] = dlogits; g.B[0] = h;
+        auto e = epi_linear<false, false, false>(dE, d);
+        RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
+    }
+    int ns, kc;
+    shard_split(Bg, Vs, d, &ns, &kc);
+    {       // dh[b, :] = sum_v dlogits[b, v] E[v, :]
+        GemmP g = gemm_defaults(Bg, d, (int)ld);
+        g.Kv = Vs; g.lda = ld; g.ldb = d; g.A[0] = dlogits; g.B[0] = E;
+        g.nsplit = ns; g.kchunk = kc;
+        auto e = epi_linear<false, false, false>(scratch, d);
+        e.c_split = (long)Bg * d;
+        RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(g, nox, e, nullptr, 1, s)));
+    }
+    const long n4 = (long)Bg * d / 4;
+    LAUNCH(shard_slab_sum_kernel, dim3(cdiv(n4, ROW_THREADS)), dim3(ROW_THREADS), 0, s, scratch, ns, n4, dh);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_shard_scatter_rows(const int64_t* ids_all, long n, int world, const float* const* stage_grads, long lo,
+                                         long Vs, long V, int d, float* dE, void* stream) {
+    if (!ids_all || n < 1 || Vs < 0 || d < 4 || (d & 3)) return -10;
+    if (Vs == 0) return 0;
+    if (!dE) return -10;
+    ShardPtrs G;
+    RET(shard_ptrs(G, stage_grads, world));
+    const int d4 = d / 4;
+    LAUNCH(shard_scatter_rows_kernel, dim3(cdiv(n * world * d4, 256)), dim3(256), 0, (hipStream_t)stream, ids_all, n, world, G, lo,
+           Vs, V, d4, dE);
+    return (int)hipGetLastError();
 }

@@ -87,6 +87,7 @@ class PeerExchange:
         self.numel = numel
         self.arena_bytes = (numel * 4 + 255) // 256 * 256
         self.ok, self.base, self.fbase, raw = self.world <= 8, None, None, None     # one xGMI node
+        self._shared = []
         if self.ok:
             base, fbase = C.c_void_p(), C.c_void_p()
             h1, h2 = C.create_string_buffer(64), C.create_string_buffer(64)
@@ -149,11 +150,42 @@ class PeerExchange:
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.group)
         return bool(flag.item() == 1.0)
 
+    def share(self, nbytes: int):
+        """One more IPC-exported allocation of ``nbytes`` per rank (the catalogue shards of bsarec_amd/catalogue.py):
+        returns (local pointer, [every rank's pointer as mapped into this process, rank order]).  Collective: every rank
+        calls it with the same size; raises on every rank if any rank failed."""
+        C_ = C
+        base, h = C_.c_void_p(), C_.create_string_buffer(64)
+        ok = self.lib.bsarec_comm_alloc(C_.byref(base), int(nbytes), 0) == 0 and \
+            self.lib.bsarec_comm_export(base.value, h) == 0
+        handles = [None] * self.world
+        torch.distributed.all_gather_object(handles, bytes(h.raw) if ok else None, group=self.group)
+        ok = ok and all(x is not None for x in handles)
+        ptrs = []
+        for r in range(self.world):
+            if r == self.rank or not ok:
+                ptrs.append(base.value)
+            else:
+                q = C_.c_void_p()
+                ok = self.lib.bsarec_comm_import(handles[r], C_.byref(q)) == 0 and ok
+                ptrs.append(q.value)
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.group)
+        if flag.item() != 1.0:
+            raise RuntimeError("peer-to-peer shared allocation failed on some rank (hipIpc export / import)")
+        self._shared.append((base.value, [q for r, q in enumerate(ptrs) if r != self.rank]))
+        return base.value, ptrs
+
     def close(self):
         if getattr(self, "base", None) is None:
             return
         try:
             torch.cuda.synchronize(self.device)
+            for own, peers in self._shared:
+                for q in peers:
+                    self.lib.bsarec_comm_release(q)
+                self.lib.bsarec_comm_free(own)
+            self._shared = []
             for r in range(self.world):
                 if r != self.rank:
                     self.lib.bsarec_comm_release(self.peer_base[r])

@@ -1,0 +1,186 @@
+"""Catalogue-sharded head (include/bsarec_shard.h, bsarec_amd/catalogue.py; SURVEY 8e, the C5 variant).
+
+1. The stand-alone entry points against the oracle's arithmetic restated with torch on the same inputs, with the W shards of one
+   table held by ONE process (the kernels only see pointers): the W partial heads together must reproduce the unsharded
+   logits / CrossEntropyLoss / gradients of src/model/bsarec.py:32-35.
+2. Two ranks on one GPU (gloo control plane, hipIpc mappings between the two processes -- the real data path): three
+   sharded steps must equal three steps of ONE process that holds the full table and trains on the global batch.
+"""
+import argparse
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _ptrs8(L, tensors):
+    return L.PTRS8(*([t.data_ptr() for t in tensors] + [None] * (8 - len(tensors))))
+
+
+@pytest.mark.parametrize("V,W,Bg,d", [(301, 2, 96, 64), (1000, 3, 40, 128), (37, 8, 16, 64), (5, 8, 8, 64)])
+def test_sharded_head_pieces_equal_the_unsharded_head(V, W, Bg, d):
+    from bsarec_amd import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(V * 7 + W)
+    E = (torch.randn(V, d, generator=g) * 0.3).to(dev)
+    h = torch.randn(Bg, d, generator=g).to(dev)
+    ans = torch.randint(0, V, (Bg,), generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    rows_per = (V + W - 1) // W
+    shards = []
+    for r in range(W):
+        t = torch.zeros(rows_per, d, device=dev)
+        lo = r * rows_per
+        vs = max(0, min(rows_per, V - lo))
+        if vs:
+            t[:vs] = E[lo:lo + vs]
+        shards.append(t)
+    # ---- lookup rows
+    n = 50
+    ids = torch.randint(0, V, (n,), generator=g).to(dev)
+    ids[::7] = 0
+    stage = torch.full((n + 1, d), 7.0, device=dev)
+    local = torch.zeros(n, dtype=torch.int64, device=dev)
+    p8 = _ptrs8(L, shards)
+    L.check(lib.bsarec_shard_gather_rows(ids.data_ptr(), n, C.byref(p8), W, rows_per, V, d, stage.data_ptr(),
+                                         local.data_ptr(), st), "gather")
+    torch.testing.assert_close(stage[0], E[0], rtol=0, atol=0)
+    nz = ids > 0
+    torch.testing.assert_close(stage[1:][nz], E[ids[nz]], rtol=0, atol=0)
+    assert torch.equal(local, torch.where(nz, torch.arange(1, n + 1, device=dev), torch.zeros_like(ids)))
+    # ---- head forward: statistics of every shard, then the combined loss
+    want_logits = h.double() @ E.double().T
+    want_lsm = torch.log_softmax(want_logits, dim=1)
+    want_rows = -want_lsm[torch.arange(Bg), ans]
+    stats_all = torch.zeros(W, 3, Bg, device=dev)
+    logits, lds = [], []
+    for r in range(W):
+        lo = r * rows_per
+        vs = max(0, min(rows_per, V - lo))
+        ld = (max(vs, 1) + 3) // 4 * 4
+        lg = torch.full((Bg, ld), 3.0, device=dev)
+        L.check(lib.bsarec_shard_logits(h.data_ptr(), d, Bg, shards[r].data_ptr(), vs, d, lg.data_ptr(), ld, st), "logits")
+        if vs:
+            torch.testing.assert_close(lg[:, :vs].double(), want_logits[:, lo:lo + vs], rtol=1e-5, atol=1e-5)
+        L.check(lib.bsarec_shard_ce_stats(lg.data_ptr(), ld, Bg, vs, ans.data_ptr(), lo, V, stats_all[r].data_ptr(), st), "stats")
+        logits.append(lg); lds.append(ld)
+    loss_rows = torch.zeros(Bg, device=dev)
+    loss = torch.zeros(1, device=dev)
+    dE_want = ((torch.softmax(want_logits, 1) - torch.nn.functional.one_hot(ans, V)) / Bg).T @ h.double()
+    dh_want = ((torch.softmax(want_logits, 1) - torch.nn.functional.one_hot(ans, V)) / Bg) @ E.double()
+    dh_sum = torch.zeros(Bg, d, device=dev, dtype=torch.float64)
+    for r in range(W):
+        lo = r * rows_per
+        vs = max(0, min(rows_per, V - lo))
+        L.check(lib.bsarec_shard_ce_grad(logits[r].data_ptr(), lds[r], Bg, vs, ans.data_ptr(), lo, V, stats_all.data_ptr(), W,
+                                         loss_rows.data_ptr(), loss.data_ptr(), st), "grad")
+        torch.testing.assert_close(loss_rows.double(), want_rows, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(loss[0].double(), want_rows.mean(), rtol=1e-5, atol=1e-5)
+        if lds[r] > vs:
+            assert float(logits[r][:, vs:].abs().max()) == 0.0          # pad columns zeroed
+        dE = torch.full((rows_per, d), 9.0, device=dev)
+        dh = torch.full((Bg, d), 9.0, device=dev)
+        scratch = torch.zeros(max(1, lib.bsarec_shard_head_bwd_scratch_floats(Bg, vs, d)), device=dev)
+        L.check(lib.bsarec_shard_head_bwd(logits[r].data_ptr(), lds[r], Bg, vs, h.data_ptr(), d, shards[r].data_ptr(), d,
+                                          dE.data_ptr(), dh.data_ptr(), scratch.data_ptr(), st), "head_bwd")
+        if vs:
+            torch.testing.assert_close(dE[:vs].double(), dE_want[lo:lo + vs], rtol=1e-4, atol=1e-6)
+        dh_sum += dh.double()
+    torch.testing.assert_close(dh_sum, dh_want, rtol=1e-4, atol=1e-6)
+    # ---- lookup-path gradient rows pulled by the owners
+    ids_all = torch.randint(0, V, (W, n), generator=g).to(dev)
+    ids_all[:, ::5] = 0
+    grads = [torch.randn(n + 1, d, generator=g).to(dev) for _ in range(W)]
+    want = torch.zeros(V, d, device=dev, dtype=torch.float64)
+    for r in range(W):
+        want.index_add_(0, ids_all[r], grads[r][1:].double())
+    want[0] = 0
+    g8 = _ptrs8(L, grads)
+    for r in range(W):
+        lo = r * rows_per
+        vs = max(0, min(rows_per, V - lo))
+        dE = torch.zeros(rows_per, d, device=dev)
+        L.check(lib.bsarec_shard_scatter_rows(ids_all.data_ptr(), n, W, C.byref(g8), lo, vs, V, d, dE.data_ptr(), st), "scatter")
+        if vs:
+            torch.testing.assert_close(dE[:vs].double(), want[lo:lo + vs], rtol=1e-5, atol=1e-5)
+        if rows_per > vs:
+            assert float(dE[vs:].abs().max()) == 0.0
+
+
+def _ns(**kw):
+    a = argparse.Namespace(item_size=301, hidden_size=64, max_seq_length=50, batch_size=32, hidden_dropout_prob=0.0,
+                           attention_probs_dropout_prob=0.0, num_hidden_layers=2, num_attention_heads=2,
+                           hidden_act="gelu", initializer_range=0.02, c=3, alpha=0.9, seed=42, lr=1e-3,
+                           adam_beta1=0.9, adam_beta2=0.999, weight_decay=0.0, no_cuda=False, log_freq=1)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _batches(ns, steps, Bg):
+    g = torch.Generator(device="cpu").manual_seed(5)
+    V, Lq = ns.item_size, ns.max_seq_length
+    out = []
+    for _ in range(steps):
+        ids = torch.randint(1, V, (Bg, Lq), generator=g)
+        pad = torch.randint(0, Lq - 2, (Bg,), generator=g)
+        ids[torch.arange(Lq)[None, :] < pad[:, None]] = 0            # left padding, as the reference's dataset
+        out.append((ids, torch.randint(1, V, (Bg,), generator=g)))
+    return out
+
+
+def _full_model(ns):
+    from bsarec_amd import BSARecModel
+    torch.manual_seed(3)
+    return BSARecModel(ns).cuda()
+
+
+def _worker(rank, world, port, kw, out_dir):
+    import torch.distributed as dist
+    from bsarec_amd.catalogue import ShardedCatalogue
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        ns = _ns(**kw)
+        B = ns.batch_size
+        sc = ShardedCatalogue(ns, B, dist.group.WORLD, "cuda:0")
+        sc.load_full_state_dict(_full_model(ns).state_dict())
+        losses = []
+        for ids, ans in _batches(ns, 3, world * B):
+            losses.append(float(sc.train_step(ids[rank * B:(rank + 1) * B], ans[rank * B:(rank + 1) * B])))
+        assert not sc.px.timed_out()
+        sd = {k: v.detach().cpu().numpy() for k, v in sc.full_state_dict().items()}
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.asarray(losses), **sd)
+        sc.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(hidden_size=128, max_seq_length=64, num_attention_heads=4, item_size=1003, c=9)],
+                         ids=["fused_d64_L50", "generic_d128_L64"])
+def test_two_ranks_sharded_catalogue_equals_the_full_table_step(kw, tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, kw, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)          # encoder replicas bit-identical; same gathered table
+    ns = _ns(**kw)
+    model = _full_model(ns)
+    model.configure_adam(lr=ns.lr, betas=(ns.adam_beta1, ns.adam_beta2), weight_decay=ns.weight_decay)
+    model.train()
+    losses = [float(model.train_step(ids.cuda(), ans.cuda())) for ids, ans in _batches(ns, 3, 2 * ns.batch_size)]
+    np.testing.assert_allclose(r0["losses"], losses, atol=2e-4)
+    sd = model.state_dict()
+    assert set(sd) == set(r0.files) - {"losses"}
+    for k in sd:
+        got, want = r0[k], sd[k].detach().cpu().numpy()
+        assert got.shape == want.shape, k
+        bad = np.abs(got - want) > 2e-5
+        assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - want).max())

@@ -46,6 +46,17 @@ def test_library_exports_every_comm_header_symbol():
         assert hasattr(lib, name), name
 
 
+def test_library_exports_every_shard_header_symbol():
+    """include/bsarec_shard.h (catalogue-sharded head): every declared entry point is exported and bound."""
+    from bsarec_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "bsarec_shard.h")).read()
+    declared = set(re.findall(r"\b(bsarec_shard_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SHARD_EXPORTS), declared ^ set(_lib.SHARD_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
 def test_workspace_query_and_shape_limits():
     import ctypes as C
     from bsarec_amd import _lib
