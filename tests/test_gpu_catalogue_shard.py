@@ -184,3 +184,59 @@ def test_two_ranks_sharded_catalogue_equals_the_full_table_step(kw, tmp_path):
         assert got.shape == want.shape, k
         bad = np.abs(got - want) > 2e-5
         assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - want).max())
+
+
+def test_one_shard_of_C5_at_its_own_shape():
+    """BASELINE.json C5 sharded 8 ways: one rank's head at ITS shape -- 1,250,001 owned rows, d = 256, the node's 8 x 256
+    sequences (10.2 GB of partial logits).  Too big for an element-wise oracle: sampled columns / rows against torch in
+    float64, the loss against a chunked logsumexp, and the split-K d h_last against a chunked matmul."""
+    from bsarec_amd import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    V, W, d, Bg = 10_000_001, 8, 256, 2048
+    rows_per = (V + W - 1) // W
+    lo, vs = 0, rows_per
+    ld = (vs + 3) // 4 * 4
+    g = torch.Generator(device="cuda").manual_seed(1)
+    E = torch.randn(rows_per, d, device=dev, generator=g) * 0.05
+    h = torch.randn(Bg, d, device=dev, generator=g)
+    ans = torch.randint(0, V, (Bg,), device=dev, generator=g)
+    ans[::2] = torch.randint(0, vs, (Bg // 2,), device=dev, generator=g)        # half of the answers owned by this rank
+    st = torch.cuda.current_stream().cuda_stream
+    logits = torch.empty(Bg, ld, device=dev)
+    stats_all = torch.zeros(W, 3, Bg, device=dev)
+    stats_all[1:, 0] = -float("inf")                   # the seven other ranks: empty statistics
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    ev[0].record()
+    L.check(lib.bsarec_shard_logits(h.data_ptr(), d, Bg, E.data_ptr(), vs, d, logits.data_ptr(), ld, st), "logits")
+    ev[1].record()
+    cols = torch.randint(0, vs, (512,), device=dev, generator=g)
+    torch.testing.assert_close(logits[:, cols].double(), h.double() @ E[cols].double().T, rtol=1e-5, atol=1e-5)
+    L.check(lib.bsarec_shard_ce_stats(logits.data_ptr(), ld, Bg, vs, ans.data_ptr(), lo, V, stats_all[0].data_ptr(), st), "stats")
+    lse = torch.cat([torch.logsumexp(logits[i:i + 128, :vs].double(), 1) for i in range(0, Bg, 128)])
+    owned = ans < vs
+    tgt = torch.where(owned, logits[torch.arange(Bg, device=dev), ans.clamp(max=vs - 1)].double(), torch.zeros_like(lse))
+    sample = logits[:, cols].clone()
+    loss_rows = torch.zeros(Bg, device=dev)
+    loss = torch.zeros(1, device=dev)
+    ev[2].record()
+    L.check(lib.bsarec_shard_ce_grad(logits.data_ptr(), ld, Bg, vs, ans.data_ptr(), lo, V, stats_all.data_ptr(), W,
+                                     loss_rows.data_ptr(), loss.data_ptr(), st), "grad")
+    ev[3].record()
+    torch.testing.assert_close(loss_rows.double(), lse - tgt, rtol=1e-5, atol=1e-5)
+    want = (torch.exp(sample.double() - lse[:, None]) - (cols[None, :] == ans[:, None]).double()) / Bg
+    torch.testing.assert_close(logits[:, cols].double(), want, rtol=1e-4, atol=1e-9)
+    dE = torch.empty(rows_per, d, device=dev)
+    dh = torch.empty(Bg, d, device=dev)
+    scratch = torch.zeros(lib.bsarec_shard_head_bwd_scratch_floats(Bg, vs, d), device=dev)
+    L.check(lib.bsarec_shard_head_bwd(logits.data_ptr(), ld, Bg, vs, h.data_ptr(), d, E.data_ptr(), d, dE.data_ptr(),
+                                      dh.data_ptr(), scratch.data_ptr(), st), "head_bwd")
+    ev[4].record()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dE[cols].double(), logits[:, cols].double().T @ h.double(), rtol=1e-4, atol=1e-9)
+    dh_want = torch.zeros(Bg, d, device=dev, dtype=torch.float64)
+    for i in range(0, vs, 131072):
+        dh_want += logits[:, i:min(i + 131072, vs)].double() @ E[i:i + 131072].double()
+    torch.testing.assert_close(dh.double(), dh_want, rtol=1e-4, atol=1e-8)
+    print("C5 shard head, ms: logits %.2f  ce_grad %.2f  head_bwd %.2f" %
+          (ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3]), ev[3].elapsed_time(ev[4])))
