@@ -342,12 +342,23 @@ def main():
             if pruned:                                                  # + the one-row top block's: 4 products over B rows, 2 over B*h
                 dw_exec += 20.0 * B * d * d + 4.0 * B * h * d * d
                 dw_alg = 24.0 * T * d * d * N / max(N - 1, 1)
-            cands = [(Lb.K_FUSED_BWD, "fused_layer_bwd_kernel (whole BSARecBlock input-gradient chain per sequence)",
-                      B * L * (24 * d * d + 8 * L * d + 16 * cb * d), None),
-                     (Lb.K_FUSED_FWD, "fused_layer_fwd_kernel (whole BSARecBlock forward per sequence)",
-                      B * L * (24 * d * d + 4 * L * d + 8 * cb * d), None),
-                     (Lb.K_DW1, "dw_direct_kernel (weight + bias gradients, direct split-K; the one-row top block's products ride in "
-                                "the next block's launch)", dw_exec, dw_alg)]
+            fwd_blk = B * L * (24 * d * d + 4 * L * d + 8 * cb * d)       # one full BSARecBlock forward / backward (input-gradient chain)
+            bwd_blk = B * L * (24 * d * d + 8 * L * d + 16 * cb * d)
+            in_block = pruned and N >= 2 and not model._plan(B).options.get("separate_top", 0)
+            if in_block:
+                # the one-row top block rides in these launches (tail of the forward, head of the backward): executed = the block
+                # below + the top block's K / V projections of all rows and its one-row vector products; algorithmic = two blocks
+                fwd_exec = fwd_blk + B * L * 4 * d * d + B * (20 * d * d + 4 * L * d)
+                bwd_exec = bwd_blk + B * (26 * d * d + 8 * L * d * h)
+                cands = [(Lb.K_FUSED_BWD, "fused_layer_bwd_kernel<head = top block> (input-gradient chain of a BSARecBlock per sequence; "
+                                          "the one-row top block's backward runs first inside the same launch)", bwd_exec, 2 * bwd_blk),
+                         (Lb.K_FUSED_FWD, "fused_layer_fwd_kernel<tail = top block> (BSARecBlock forward per sequence; the one-row top "
+                                          "block's forward runs as the tail of the same launch)", fwd_exec, 2 * fwd_blk)]
+            else:
+                cands = [(Lb.K_FUSED_BWD, "fused_layer_bwd_kernel (whole BSARecBlock input-gradient chain per sequence)", bwd_blk, None),
+                         (Lb.K_FUSED_FWD, "fused_layer_fwd_kernel (whole BSARecBlock forward per sequence)", fwd_blk, None)]
+            cands.append((Lb.K_DW1, "dw_direct_kernel (weight + bias gradients, direct split-K; the one-row top block's products ride in "
+                                    "the next block's launch)", dw_exec, dw_alg))
         else:
             cands = [(Lb.K_FFN1, "gemm_kernel<NT, EpiLinear<bias>> (FFN dense_1)", 2.0 * T * d * 4 * d, None),
                      (Lb.K_DW1, "gemm_grouped_tn_kernel (6 weight + bias gradients of a block, split-K)", 24.0 * T * d * d, None)]
@@ -398,10 +409,14 @@ def main():
                 src += ", this build)" if sha == Lb.source_sha16() else f", this build is {Lb.source_sha16()}: kernels changed since)"
                 return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, src
             return None, None
-        traffic, tsrc = pmc_traffic(top["kernel"].split(" ")[0])
+        traffic, tsrc = pmc_traffic(top["kernel"].split(" ")[0].split("<")[0])
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"],
                            "peak": peak, "unit": "TFLOP/s",
                            "frac": round(top["achieved"] / peak, 5),
+                           "flops_counted": "executed (the FLOPs this launch really issues); algorithmic_* = the un-pruned count of "
+                                            "the blocks the launch stands for",
+                           "algorithmic_achieved": top.get("algorithmic_achieved"),
+                           "algorithmic_frac": round(top["algorithmic_achieved"] / peak, 5) if top.get("algorithmic_achieved") else None,
                            "traffic": traffic, "traffic_source": tsrc,
                            "avg_us": top["avg_us"], "event_overhead_us": round(ovh_s * 1e6, 3), "launches_per_step": top["launches_per_step"],
                            "flops_per_launch": top["flops_per_launch"], "other_kernels": rows[1:]}

@@ -524,7 +524,10 @@ static int launch_freq_bwd(const float* X, const float* dF, const float* dXin, c
 
 static bool fused_ok(const bsarec_plan& p) { return p.fused; }
 
-static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const int64_t* ids = nullptr, const GatherP* gp = nullptr) {
+static void fill_top_fwd(bsarec_plan& p, int l, bool tr, TopFwdP& F);
+
+static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const int64_t* ids = nullptr, const GatherP* gp = nullptr,
+                            bool top_tail = false /* block l + 1 is the pruned top block: run it as this launch's tail */) {
     const bsarec_config_t& c = p.cfg;
     const bsarec_layer_t& w = p.P.layer[l];
     const bsarec_layer_t& wm = p.bf ? p.S.layer[l] : w;      // MFMA operands: bf16 shadow of the Linear weights (storage = 1)
@@ -554,19 +557,25 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
     F.trash = p.trash;
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
     const size_t smem = fused_fwd_smem_bytes();
+    TopFwdP TF;
+    if (top_tail) fill_top_fwd(p, l + 1, tr, TF);
 #define FUSED_FWD_CASE(DHV, BFV) { \
-        static bool attr = false; \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV>), \
+        static bool attr = false, attr_t = false; \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV, NoTail>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
+        if (!attr_t) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV, TopFwdP>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_t = true; } \
         ProfScope prof(BSAREC_K_FUSED_FWD, s); \
-        LAUNCH((fused_layer_fwd_kernel<DHV, BFV>), dim3(c.batch), dim3(512), smem, s, F); }
+        if (top_tail) LAUNCH((fused_layer_fwd_kernel<DHV, BFV, TopFwdP>), dim3(c.batch), dim3(512), smem, s, F, TF); \
+        else LAUNCH((fused_layer_fwd_kernel<DHV, BFV, NoTail>), dim3(c.batch), dim3(512), smem, s, F, NoTail()); }
     if (p.bf) { if (p.dh == 16) FUSED_FWD_CASE(16, true) else if (p.dh == 32) FUSED_FWD_CASE(32, true) else FUSED_FWD_CASE(64, true) }
     else { if (p.dh == 16) FUSED_FWD_CASE(16, false) else if (p.dh == 32) FUSED_FWD_CASE(32, false) else FUSED_FWD_CASE(64, false) }
 #undef FUSED_FWD_CASE
     return (int)hipGetLastError();
 }
 
-static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, float* dXout, hipStream_t s, bool top) {
+static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, float* dXout, hipStream_t s, bool top,
+                            const TopBwdP* head = nullptr /* the pruned top block's backward runs as this launch's head */) {
     const bsarec_config_t& c = p.cfg;
     const bsarec_layer_t& w = p.P.layer[l];
     const bsarec_layer_t& wm = p.bf ? p.S.layer[l] : w;
@@ -597,21 +606,23 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     const size_t smem = fused_bwd_smem_bytes();
 #define FUSED_BWD_CASE(DHV, BFV) { \
         static bool attr = false; \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV>), \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV, NoTail>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+                     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV, TopBwdP>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
         ProfScope prof(BSAREC_K_FUSED_BWD, s); \
-        LAUNCH((fused_layer_bwd_kernel<DHV, BFV>), dim3(c.batch), dim3(512), smem, s, F); }
+        if (head) LAUNCH((fused_layer_bwd_kernel<DHV, BFV, TopBwdP>), dim3(c.batch), dim3(512), smem, s, F, *head); \
+        else LAUNCH((fused_layer_bwd_kernel<DHV, BFV, NoTail>), dim3(c.batch), dim3(512), smem, s, F, NoTail()); }
     if (p.bf) { if (p.dh == 16) FUSED_BWD_CASE(16, true) else if (p.dh == 32) FUSED_BWD_CASE(32, true) else FUSED_BWD_CASE(64, true) }
     else { if (p.dh == 16) FUSED_BWD_CASE(16, false) else if (p.dh == 32) FUSED_BWD_CASE(32, false) else FUSED_BWD_CASE(64, false) }
 #undef FUSED_BWD_CASE
     return (int)hipGetLastError();
 }
 
-static int launch_top_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
+static void fill_top_fwd(bsarec_plan& p, int l, bool tr, TopFwdP& F) {
     const bsarec_config_t& c = p.cfg;
     const bsarec_layer_t& w = p.P.layer[l];
     LayerBufs& b = p.lb[l];
-    TopFwdP F;
     memset(&F, 0, sizeof(F));
     F.X = p.X[l]; F.Xout = p.X[l + 1];
     F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.f_b = w.filter_ln_b;
@@ -628,6 +639,12 @@ static int launch_top_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
+}
+
+static int launch_top_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
+    const bsarec_config_t& c = p.cfg;
+    TopFwdP F;
+    fill_top_fwd(p, l, tr, F);
     const size_t smem = top_fwd_smem_bytes();
 #define TOP_FWD_CASE(DHV, BFV) { \
         static bool attr = false; \
@@ -640,12 +657,11 @@ static int launch_top_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStream_t s) {
+static void fill_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, TopBwdP& F) {
     const bsarec_config_t& c = p.cfg;
     const bsarec_layer_t& w = p.P.layer[l];
     LayerBufs& b = p.lb[l];
     const long nb = p.nblk, d = c.hidden;
-    TopBwdP F;
     memset(&F, 0, sizeof(F));
     F.dX = dXout; F.X = p.X[l];
     F.sqrt_beta = w.sqrt_beta; F.f_g = w.filter_ln_w; F.wq = w.query_w; F.wk = w.key_w; F.wv = w.value_w; F.wo = w.dense_w;
@@ -664,6 +680,12 @@ static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStrea
     F.drop_f = make_drop(p, c.p_hidden, 1 + 4 * l, tr); F.drop_p = make_drop(p, c.p_attn, 2 + 4 * l, tr);
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l + 1) : nullptr;
+}
+
+static int launch_top_bwd(bsarec_plan& p, int l, bool tr, float* dXout, hipStream_t s) {
+    const bsarec_config_t& c = p.cfg;
+    TopBwdP F;
+    fill_top_bwd(p, l, tr, dXout, F);      // (reads p.part_ln / p.part_beta of THIS layer: call inside the layer's iteration)
     const size_t smem = top_bwd_smem_bytes();
 #define TOP_BWD_CASE(DHV, BFV) { \
         static bool attr = false; \
@@ -727,8 +749,9 @@ static int forward_impl(bsarec_plan_t* p, const int64_t* ids, int train, void* s
         LayerBufs& b = p->lb[l];
         const float* X = p->X[l];
         if (fused_ok(*p)) {
-            if (p->pruned && l == c.layers - 1) RET(launch_top_fwd(*p, l, tr, s));
-            else RET(launch_fused_fwd(*p, l, tr, s, ids, (l == 0 && embed_in_block) ? &gp : nullptr));
+            const bool tail = p->pruned && c.layers >= 2 && !c.separate_top;     // top block = tail of the launch below it
+            if (p->pruned && l == c.layers - 1) { if (!tail) RET(launch_top_fwd(*p, l, tr, s)); }
+            else RET(launch_fused_fwd(*p, l, tr, s, ids, (l == 0 && embed_in_block) ? &gp : nullptr, tail && l == c.layers - 2));
             continue;
         }
         // K2 FrequencyLayer
@@ -973,6 +996,8 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
     DwP DW;                       // weight-gradient problems waiting for their launch (dw_direct.h)
     memset(&DW, 0, sizeof(DW));
     int dw_np = 0, dw_nu = 0;
+    TopBwdP top_head;
+    bool have_head = false;
     for (int l = N - 1; l >= 0; --l) {
         const bsarec_layer_t& w = p->P.layer[l];
         LayerBufs& b = p->lb[l];
@@ -981,9 +1006,12 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
         p->slab_w = p->slab_wL[l]; p->slab_b = p->slab_bL[l]; p->part_ln = p->part_lnL[l]; p->part_beta = p->part_betaL[l];
         const bool top_pruned = p->fused && p->pruned && l == N - 1;
         if (top_pruned) {
-            RET(launch_top_bwd(*p, l, tr, dXout, s));
+            // rides in the next launch -- when this layer's weight-gradient products do too (the direct kernel defers them; the
+            // tiled fallback launches them inside this iteration and needs the top block's operands now)
+            if (N >= 2 && !c.separate_top && p->direct_dw) { fill_top_bwd(*p, l, tr, dXout, top_head); have_head = true; }
+            else RET(launch_top_bwd(*p, l, tr, dXout, s));
         } else if (p->fused) {
-            RET(launch_fused_bwd(*p, l, tr, dY, dXout, s, l == N - 1 && !p->ext_dy));
+            RET(launch_fused_bwd(*p, l, tr, dY, dXout, s, l == N - 1 && !p->ext_dy, (have_head && l == N - 2) ? &top_head : nullptr));
         } else {
         // ---- FeedForward backward
         {

@@ -279,7 +279,8 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, cons
                                            const float* __restrict__ beta, float eps, const float* __restrict__ dsp,
                                            float alpha, float oma, long tok0, int L, float* __restrict__ outL,
                                            float* __restrict__ outG, float* __restrict__ xhatG, float* __restrict__ rstdG,
-                                           bool out_f32 = false /* BF: outG is an fp32 tensor (the last layer's output) */) {
+                                           bool out_f32 = false /* BF: outG is an fp32 tensor (the last layer's output) */,
+                                           bool round_outL = false /* BF: the LDS copy holds what a reader of outG would see */) {
     const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
     const int rpp = blockDim.x >> 4;
     const f32x4 bi = gld4(bias + lc), g = gld4(gamma + lc), be = gld4(beta + lc);
@@ -303,9 +304,29 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, cons
             if (BF && out_f32) gst4(outG + e, y); else ast4<BF>(outG, e, y);
             if (lc == 0) gst(rstdG + tok0 + r, rs);
         }
+        if (BF && round_outL) {
+            const unsigned a = pk_bf16(y.x, y.y), c = pk_bf16(y.z, y.w);
+            y = f32x4{bf_lo(a), bf_hi(a), bf_lo(c), bf_hi(c)};
+        }
         if (outL) st4(outL + r * FS + lc, y);
     }
 }
+
+// The one-row top block as the tail of this kernel (fused_top.h; declared here, defined there).
+struct NoTail {};
+template <bool BF> struct TopFwdRegs;
+template <bool BF, unsigned KOFF> __device__ __forceinline__ void top_fwd_prefetch(TopFwdRegs<BF>& R);
+template <int DH, bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const DropSeed& dseed, float* sX, float* sK, float* sV,
+                                             float* sPart, float* sTab, float* sSpec, float* sVec, const int* sIds);
+template <class T> struct IsTail { static constexpr bool value = true; };
+template <> struct IsTail<NoTail> { static constexpr bool value = false; };
+// ... and its backward as the head of this block's backward kernel.  Waves 4..7 of that kernel execute exactly
+// TOP_BWD_BARRIERS barriers while waves 0..3 run top_bwd_body (which contains that many, all unconditional).
+constexpr int TOP_BWD_BARRIERS = 11;
+template <int DH, bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, float* sK, float* sV, const float* sTab, float* sVec,
+                                             float* sDX);
 
 
 // Forward: 8 waves = 2 groups of 4 (each group tiles 64 tokens x 64 features as 2 x 2 waves), two waves per SIMD
@@ -315,10 +336,15 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, cons
 //     row max / sum are exchanged through LDS, the two partial contexts are summed in a row pass;
 //   * dense and dense_2 split K across the groups (two partial tiles, summed by the LayerNorm row pass),
 //     dense_1 splits its four 64-wide output blocks.
-template <int DH, bool BF>
+// TAILP = TopFwdP: the block above is the one-row top block of the loss path and runs as this kernel's tail -- the
+// output tile, the ids and the twiddle table stay in LDS, waves 4..7 exit, waves 0..3 carry on (one launch and the
+// top block's whole load phase saved).
+template <int DH, bool BF, class TAILP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-fused_layer_fwd_kernel(const FusedFwdP P_unused) {
+fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
 #define PTYPE FusedFwdP
+    constexpr bool TAIL = IsTail<TAILP>::value;
+    constexpr unsigned KOFF = (unsigned)((sizeof(FusedFwdP) + 7) & ~(size_t)7);     // kernarg offset of T_unused
     const auto R0_L = KARG(FusedFwdP, L);
     const auto R0_Lp = KARG(FusedFwdP, Lp);
     const auto R0_cb = KARG(FusedFwdP, cb);
@@ -777,6 +803,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     }
     lds_barrier();
     STAMP(7);
+    TopFwdRegs<BF> TR;
+    if constexpr (TAIL) { if (wave < 4) top_fwd_prefetch<BF, KOFF>(TR); }
     const auto R7_Xout = KARG(FusedFwdP, Xout);
     const auto R7_b2 = KARG(FusedFwdP, b2);
     const auto R7_drop_ff = KARG(FusedFwdP, drop_ff);
@@ -785,9 +813,16 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused) {
     const auto R7_ff_g = KARG(FusedFwdP, ff_g);
     const auto R7_rstd_ff = KARG(FusedFwdP, rstd_ff);
     const auto R7_xhat_ff = KARG(FusedFwdP, xhat_ff);
-    ln_rows_64<false, BF>(sX, sE, R7_b2, sH, R7_drop_ff, dseed, R7_ff_g, R7_ff_b, R7_eps, nullptr, 0.f, 1.f, tok0, L, nullptr, R7_Xout,
-                          R7_xhat_ff, R7_rstd_ff, KARG(FusedFwdP, xout_f32) != 0);
+    ln_rows_64<false, BF>(sX, sE, R7_b2, sH, R7_drop_ff, dseed, R7_ff_g, R7_ff_b, R7_eps, nullptr, 0.f, 1.f, tok0, L,
+                          TAIL ? sD : nullptr, R7_Xout, R7_xhat_ff, R7_rstd_ff, KARG(FusedFwdP, xout_f32) != 0, TAIL);
     STAMP(8);
+    if constexpr (TAIL) {
+        // x tile of the top block = sD; K, V tiles and the DFT partials alias the dead feed-forward tile; row vectors alias
+        // tile 0 (read by the row pass above until the barrier)
+        lds_barrier();
+        if (wave >= 4) return;
+        top_fwd_rest<DH, BF, KOFF>(TR, dseed, sD, sR, sR + TS, sR + 2 * TS, sTab, sSpec, sX, sIds);
+    }
 }
 #undef PTYPE
 
@@ -873,10 +908,14 @@ __device__ __forceinline__ void seq_partials_64(const f32x4 (&v)[N], float* cons
 // dH, dC and the QKV input-gradient split K (two partial tiles, summed by the next row pass); attention backward
 // runs (query tile, key tile) per wave and the 6 dQ/dK/dV tiles of a head on 6 of the 8 waves; the two DFT
 // sources of the FrequencyLayer backward run one per group.
-template <int DH, bool BF>
+// HEADP = TopBwdP: the block above is the one-row top block of the loss path; its backward runs first, inside this
+// kernel, on waves 0..3 (its dX tile stays in LDS), while waves 4..7 stage this block's gelu' tile.
+template <int DH, bool BF, class HEADP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-fused_layer_bwd_kernel(const FusedBwdP P_unused) {
+fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
 #define PTYPE FusedBwdP
+    constexpr bool HEAD = IsTail<HEADP>::value;
+    constexpr unsigned KOFF = (unsigned)((sizeof(FusedBwdP) + 7) & ~(size_t)7);     // kernarg offset of H_unused
     const auto R0_L = KARG(FusedBwdP, L);
     const auto R0_Lp = KARG(FusedBwdP, Lp);
     const auto R0_cb = KARG(FusedBwdP, cb);
@@ -923,9 +962,32 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
     const auto R1_tw = KARG(FusedBwdP, tw);
     const auto R1_w2 = KARG(FusedBwdP, w2);
     const auto R1_xhat_ff = KARG(FusedBwdP, xhat_ff);
+    build_twiddle_table(R1_tw, L, cb, sTab);
+    if constexpr (HEAD) {
+        lds_barrier();                                  // the twiddle table is complete
+        if (wave < 4) {
+            // top block's tiles alias T6..T8, its row vectors T0, its dX tile T1 (= this block's dY); T2..T5 stay free for
+            // the gelu' tile the other waves are staging
+            top_bwd_body<DH, BF, KOFF>(dseed, sG, sdF, sPm, sTab, sAcc, sT);
+        } else {
+            const float* gu = KARG(FusedBwdP, u);
+            f32x4 uw[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = (tid - 256) + i * 256, r = idx >> 6, c4 = (idx & 63) << 2;
+                uw[i] = ald4<BF>(gu, (tok0 + min(r, L - 1)) * 256 + c4);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = (tid - 256) + i * 256, r = idx >> 6, c4 = (idx & 63) << 2;
+                st4(sdU + r * FU + c4, r < L ? uw[i] : f32x4{0, 0, 0, 0});
+            }
+#pragma unroll 1
+            for (int i = 0; i < TOP_BWD_BARRIERS; ++i) lds_barrier();
+        }
+    }
     WFrag<BF, 64> wA, wB;
     load_wT<BF, 64, 256>(R1_w2, (long)KH * 256 + 128 * grp + col, wA);             // first dU block of this group
-    build_twiddle_table(R1_tw, L, cb, sTab);
     // stage A1's operands are requested BEFORE the u tile: loads return in issue order, so the LayerNorm row pass waits
     // only for them while the 64 KB of u are still in flight
     const f32x4 g = gld4(R1_ff_g + lc);
@@ -945,12 +1007,16 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
         } else {                                        // branch-free (rows past L re-read row L-1, then zeroed)
             const bool ok = r < L;
             const long ec = (tok0 + min(r, L - 1)) * 64 + lc;
-            const f32x4 d4 = ald4<BF>(R1_dY, ec), x4 = ald4<BF>(R1_xhat_ff, ec);
+            f32x4 d4 = {0, 0, 0, 0};                    // HEAD: the upstream gradient comes out of the head below, through LDS
+            if constexpr (!HEAD) d4 = ald4<BF>(R1_dY, ec);
+            const f32x4 x4 = ald4<BF>(R1_xhat_ff, ec);
             const float r1 = gld(R1_rstd_ff + tok0 + min(r, L - 1));
+            if constexpr (HEAD) d4 = ld4(sT + r * FS + lc);          // the head's dX tile
             dy[i] = ok ? d4 : f32x4{0, 0, 0, 0}; xh[i] = ok ? x4 : f32x4{0, 0, 0, 0}; rs[i] = ok ? r1 : 0.f;
         }
     }
     f32x4 uv[8];
+    if constexpr (!HEAD)
     {   // gelu'(pre-activation) tile [64][256] (saved by the forward) -> registers now, LDS after stage A1's row pass; consumed by stage A2
         const float* gu = KARG(FusedBwdP, u);
         // branch-free: a predicated load becomes a branch and the loop then waits for every load before issuing the next
@@ -988,10 +1054,12 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused) {
             seq_partials_64<2>(pv, pr, pd);
         }
     }
+    if constexpr (!HEAD) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = tid + i * 512, r = idx >> 6, c4 = (idx & 63) << 2;
         st4(sdU + r * FU + c4, r < L ? uv[i] : f32x4{0, 0, 0, 0});
+    }
     }
     lds_barrier();
 

@@ -86,60 +86,57 @@ __device__ __forceinline__ void ln_row(float v, float eps, float& xhat, float& r
     xhat = dl * rstd;
 }
 
-template <int DH, bool BF>
-__global__ void __launch_bounds__(256)
-top_fwd_kernel(const TopFwdP P) {
-#define PTYPE TopFwdP
-    constexpr int TS = 64 * FS;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sX = sm;                       // x tile
-    float* sK = sm + TS;                  // K tile [token][feature]
-    float* sV = sm + 2 * TS;              // V tile [token][feature]
-    float* sPart = sm + 3 * TS;           // DFT partials [16][4][2][64] = 8192 floats
-    float* sTab = sPart + 8192;           // FUSED_MAX_CB * 128
-    float* sSpec = sTab + FUSED_MAX_CB * 128;   // FUSED_MAX_CB * 128
-    float* sVec = sSpec + FUSED_MAX_CB * 128;   // row vectors: [0]=q [64]=pd(h*64) [320]=ctx [384]=hmix [448]=g(256) [704]=dsp
-    int* sIds = reinterpret_cast<int*>(sVec + 768);
-    float* sQ = sVec; float* sPd = sVec + 64; float* sCtx = sVec + 320; float* sHm = sVec + 384; float* sG = sVec + 448;
-    float* sDsp = sVec + 704;
+// The forward of the top block in two pieces so that it can also run as the TAIL of the block below it
+// (fused_layer_fwd_kernel<.., TAIL = true>: the lower block's output tile, ids and twiddle table are already in LDS, waves
+// 4..7 of that kernel have exited, and the loads of top_fwd_prefetch were issued before the lower block's last row pass).
+// Parameters are read from the kernarg segment at byte offset KOFF (0 for the stand-alone kernel; behind FusedFwdP for
+// the tail) at their point of use -- see KARG in fused_layer.h.
+#define TP(f) kernarg_field<decltype(TopFwdP::f)>(KOFF + (unsigned)offsetof(TopFwdP, f))
+#define TSTAMP(i) do { long long* st_ = TP(stamps); if (st_ && blockIdx.x == 0 && threadIdx.x == 0) st_[i] = clock64(); } while (0)
 
+template <bool BF>
+struct TopFwdRegs {
+    WFrag<BF, 64> wA, wB;                  // K / V weight fragments of this wave's two 32 x 32 tiles
+    f32x4 wq4[4], wo4[4];                  // weight rows of the one-row query / dense products
+    float bias_k, bias_v, bq_n, bo_n, b1_n, b2_n;
+    float c_beta, c_fg, c_fb, c_ag, c_ab, c_ffg, c_ffb;
+};
+
+template <bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_fwd_prefetch(TopFwdRegs<BF>& R) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    STAMP(0);
-    const int L = P.L, Lp = P.Lp, heads = P.heads, cb = P.cb;
-    const int b = blockIdx.x, tl = L - 1;
-    const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
-
-    // Loads return in issue order (vmcnt): the dropout seed and the small per-column vectors of the row steps go first
-    // so that no later step waits behind a bulk weight prefetch for them.
-    const DropSeed dseed = drop_seed(KARG(TopFwdP, drop_f));
-    const float c_beta = gld(P.sqrt_beta + lane), c_fg = gld(P.f_g + lane), c_fb = gld(P.f_b + lane), c_ag = gld(P.a_g + lane),
-                c_ab = gld(P.a_b + lane), c_ffg = gld(P.ff_g + lane), c_ffb = gld(P.ff_b + lane);
-    // ---- load: x tile, ids, twiddles; K / V weight fragments for this wave's two 32 x 32 tiles
-    const int wm = wave >> 1, wn = wave & 1, col = wn * 32 + l31;
+    // Loads return in issue order (vmcnt): the small per-column vectors of the row steps go first so that no later step
+    // waits behind a bulk weight prefetch for them.
+    R.c_beta = gld(TP(sqrt_beta) + lane); R.c_fg = gld(TP(f_g) + lane); R.c_fb = gld(TP(f_b) + lane);
+    R.c_ag = gld(TP(a_g) + lane); R.c_ab = gld(TP(a_b) + lane); R.c_ffg = gld(TP(ff_g) + lane); R.c_ffb = gld(TP(ff_b) + lane);
+    const int wn = wave & 1, col = wn * 32 + l31;
     const int KH = (BF ? 8 : 4) * half;
     const long wrow = (long)col * 64 + KH;
-    WFrag<BF, 64> wA, wB;
-    load_w<BF, 64>(BF ? P.wk_sh : P.wk, wrow, wA);
-    load_w<BF, 64>(BF ? P.wv_sh : P.wv, wrow, wB);
-    const float bias_k = gld(P.bk + col), bias_v = gld(P.bv + col);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
-        f32x4 v = ald4<BF>(P.X, (tok0 + min(r, L - 1)) * 64 + c4);      // branch-free: rows past L re-read row L-1, zeroed
-        if (r >= L) v = f32x4{0, 0, 0, 0};
-        st4(sX + r * FS + c4, v);
-    }
-    // weight rows of the one-row products, requested now (query, dense) and after the MFMA phase (feed-forward)
+    load_w<BF, 64>(BF ? TP(wk_sh) : TP(wk), wrow, R.wA);
+    load_w<BF, 64>(BF ? TP(wv_sh) : TP(wv), wrow, R.wB);
+    R.bias_k = gld(TP(bk) + col); R.bias_v = gld(TP(bv) + col);
     const int on = tid >> 2, osl = tid & 3;
-    f32x4 wq4[4], wo4[4];
-    gemv_rows_load<64, 4>(P.wq, 64, on, osl, wq4);
-    gemv_rows_load<64, 4>(P.wo, 64, on, osl, wo4);
-    const float bq_n = gld(P.bq + on), bo_n = gld(P.bo + on), b1_n = gld(P.b1 + tid), b2_n = gld(P.b2 + on);
-    if (tid < 64) sIds[tid] = tid < L ? gldi(P.ids32 + (tok0 + tid)) : 0;
-    build_twiddle_table(P.tw, L, cb, sTab);
-    lds_barrier();
-    STAMP(1);
+    gemv_rows_load<64, 4>(TP(wq), 64, on, osl, R.wq4);
+    gemv_rows_load<64, 4>(TP(wo), 64, on, osl, R.wo4);
+    R.bq_n = gld(TP(bq) + on); R.bo_n = gld(TP(bo) + on); R.b1_n = gld(TP(b1) + tid); R.b2_n = gld(TP(b2) + on);
+}
+
+// sX: x tile (rows >= L zero), sIds, sTab filled by the caller; everything else is scratch of this function.
+// 256 threads (waves 0..3 of the workgroup; any other wave must have exited: the barriers count the live waves).
+template <int DH, bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const DropSeed& dseed, float* sX, float* sK, float* sV,
+                                             float* sPart, float* sTab, float* sSpec, float* sVec, const int* sIds) {
+    float* sQ = sVec; float* sPd = sVec + 64; float* sCtx = sVec + 320; float* sHm = sVec + 384; float* sG = sVec + 448;
+    float* sDsp = sVec + 704;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int L = TP(L), Lp = TP(Lp), heads = TP(heads), cb = TP(cb);
+    const int b = blockIdx.x, tl = L - 1;
+    const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
+    const int wm = wave >> 1, wn = wave & 1, col = wn * 32 + l31;
+    const int KH = (BF ? 8 : 4) * half;
+    const int on = tid >> 2, osl = tid & 3;
 
     // ---- K, V projections of all rows (MFMA), spectrum of x (VALU)
     {
@@ -147,26 +144,27 @@ top_fwd_kernel(const TopFwdP P) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w<BF, 64>(sX + arow, wA, acc);
+        mma_w<BF, 64>(sX + arow, R.wA, acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sK[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + bias_k;
+        for (int r = 0; r < 16; ++r) sK[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + R.bias_k;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w<BF, 64>(sX + arow, wB, acc);
+        mma_w<BF, 64>(sX + arow, R.wB, acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sV[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + bias_v;
+        for (int r = 0; r < 16; ++r) sV[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + R.bias_v;
     }
     auto xsrc = [&](int, int t, int lc) { return ld4(sX + t * FS + lc); };
     dft_spectrum_tab<1>(xsrc, L, cb, sTab, sSpec, sPart);        // ends with a barrier: sK / sV complete too
 
     // q_last = x_last . Wq^T + bq  (4 lanes per output), and the k, v rows -> global (the backward reads them)
     {
-        const float qv = gemv_rows_dot<64, 4>(wq4, sX + tl * FS, osl) + bq_n;
-        if (osl == 0) { sQ[on] = qv; ast<BF>(P.q, el + on, qv); }
+        const float qv = gemv_rows_dot<64, 4>(R.wq4, sX + tl * FS, osl) + R.bq_n;
+        float* const Pq = TP(q); float* const Pk = TP(k); float* const Pv = TP(v);
+        if (osl == 0) { sQ[on] = qv; ast<BF>(Pq, el + on, qv); }
         const int lr = tid >> 4, lc = (tid & 15) << 2;
         for (int r = lr; r < L; r += 16) {
-            ast4<BF>(P.k, (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
-            ast4<BF>(P.v, (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
+            ast4<BF>(Pk, (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
+            ast4<BF>(Pv, (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
         }
     }
     // FrequencyLayer output of the last row (wave 0, lane = column):  src/model/bsarec.py:90-104
@@ -175,22 +173,22 @@ top_fwd_kernel(const TopFwdP P) {
         const f32x4 low4 = lowpass_tab(sSpec, tl, c4, L, cb, sTab);
         const float low = (c & 3) == 0 ? low4.x : (c & 3) == 1 ? low4.y : (c & 3) == 2 ? low4.z : low4.w;
         const float xv = sX[tl * FS + c];
-        gst(P.low + el + c, low);
-        const float bt = c_beta;
+        gst(TP(low) + el + c, low);
+        const float bt = R.c_beta;
         const float f = low + bt * bt * (xv - low);
-        const float v = f * drop_mult1(KARG(TopFwdP, drop_f), dseed, (uint64_t)(el + c)) + xv;
+        const float v = f * drop_mult1(TP(drop_f), dseed, (uint64_t)(el + c)) + xv;
         float xh, rs;
-        ln_row(v, P.eps, xh, rs);
-        ast<BF>(P.xhat_f, el + c, xh);
-        if (c == 0) gst(P.rstd_f + tok0 + tl, rs);
-        sDsp[c] = c_fg * xh + c_fb;
+        ln_row(v, TP(eps), xh, rs);
+        ast<BF>(TP(xhat_f), el + c, xh);
+        if (c == 0) gst(TP(rstd_f) + tok0 + tl, rs);
+        sDsp[c] = R.c_fg * xh + R.c_fb;
     }
     lds_barrier();
-    STAMP(2);
+    TSTAMP(2);
     // feed-forward weight rows: requested here (nothing below loads from global memory until they are used)
     f32x4 w1r[16], w2r[16];
-    gemv_rows_load<64, 1>(P.w1, 64, tid, 0, w1r);
-    gemv_rows_load<256, 4>(P.w2, 256, on, osl, w2r);
+    gemv_rows_load<64, 1>(TP(w1), 64, tid, 0, w1r);
+    gemv_rows_load<256, 4>(TP(w2), 256, on, osl, w2r);
 
     // ---- attention row of the last query: one wave per head, lane = key        src/model/_modules.py:118-135
     if (wave < heads) {
@@ -211,11 +209,11 @@ top_fwd_kernel(const TopFwdP P) {
         const float e = key < L ? __expf(s - mx) : 0.f;
         const float p = e / group_sum<64>(e);
         const long pe = (((long)b * heads + head) * L + tl) * Lp;
-        if (key < Lp) ast<BF>(P.probs, pe + key, p);
-        sPd[head * 64 + key] = key < L ? p * drop_mult1(KARG(TopFwdP, drop_p), dseed, (uint64_t)(pe + key)) : 0.f;
+        if (key < Lp) ast<BF>(TP(probs), pe + key, p);
+        sPd[head * 64 + key] = key < L ? p * drop_mult1(TP(drop_p), dseed, (uint64_t)(pe + key)) : 0.f;
     }
     lds_barrier();
-    STAMP(3);
+    TSTAMP(3);
     if (tid < 64) {                               // ctx_last[c] = sum_j Drop(p)_j v_j[c]
         const int c = tid, head = c / DH;
         float acc = 0.f;
@@ -224,59 +222,96 @@ top_fwd_kernel(const TopFwdP P) {
         for (int j = 0; j < 64; ++j) a4[j & 3] += sPd[head * 64 + j] * sV[j * FS + c];
         acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         sCtx[c] = acc;
-        ast<BF>(P.ctx, el + c, acc);
+        ast<BF>(TP(ctx), el + c, acc);
     }
     lds_barrier();
-    STAMP(4);
+    TSTAMP(4);
 
     // ---- dense + dropout + residual + LayerNorm + alpha mix (one row)
     {
-        const float o = gemv_rows_dot<64, 4>(wo4, sCtx, osl) + bo_n;
+        const float o = gemv_rows_dot<64, 4>(R.wo4, sCtx, osl) + R.bo_n;
         if (osl == 0) sG[on] = o;
     }
     lds_barrier();
-    STAMP(5);
+    TSTAMP(5);
     if (wave == 0) {
         const int c = lane;
-        const float v = sG[c] * drop_mult1(KARG(TopFwdP, drop_o), dseed, (uint64_t)(el + c)) + sX[tl * FS + c];
+        const float v = sG[c] * drop_mult1(TP(drop_o), dseed, (uint64_t)(el + c)) + sX[tl * FS + c];
         float xh, rs;
-        ln_row(v, P.eps, xh, rs);
-        ast<BF>(P.xhat_a, el + c, xh);
-        if (c == 0) gst(P.rstd_a + tok0 + tl, rs);
-        const float a = c_ag * xh + c_ab;
-        const float hm = P.alpha * sDsp[c] + P.oma * a;
+        ln_row(v, TP(eps), xh, rs);
+        ast<BF>(TP(xhat_a), el + c, xh);
+        if (c == 0) gst(TP(rstd_a) + tok0 + tl, rs);
+        const float a = R.c_ag * xh + R.c_ab;
+        const float hm = TP(alpha) * sDsp[c] + TP(oma) * a;
         sHm[c] = hm;
-        ast<BF>(P.hmix, el + c, hm);
+        ast<BF>(TP(hmix), el + c, hm);
     }
     lds_barrier();
-    STAMP(6);
+    TSTAMP(6);
 
     // ---- feed-forward (one row): u = hmix W1^T + b1 (one output per thread), y = gelu(u) W2^T + b2
     {
-        const float u = gemv_rows_dot<64, 1>(w1r, sHm, 0) + b1_n;
-        ast<BF>(P.u, (tok0 + tl) * 256 + tid, u);
+        const float u = gemv_rows_dot<64, 1>(w1r, sHm, 0) + R.b1_n;
+        ast<BF>(TP(u), (tok0 + tl) * 256 + tid, u);
         sG[tid] = gelu_f(u);
     }
     lds_barrier();
-    STAMP(7);
+    TSTAMP(7);
     {
-        const float y = gemv_rows_dot<256, 4>(w2r, sG, osl) + b2_n;
+        const float y = gemv_rows_dot<256, 4>(w2r, sG, osl) + R.b2_n;
         if (osl == 0) sQ[on] = y;
     }
     lds_barrier();
-    STAMP(8);
+    TSTAMP(8);
     if (wave == 0) {
         const int c = lane;
-        const float v = sQ[c] * drop_mult1(KARG(TopFwdP, drop_ff), dseed, (uint64_t)(el + c)) + sHm[c];
+        const float v = sQ[c] * drop_mult1(TP(drop_ff), dseed, (uint64_t)(el + c)) + sHm[c];
         float xh, rs;
-        ln_row(v, P.eps, xh, rs);
-        ast<BF>(P.xhat_ff, el + c, xh);
-        if (c == 0) gst(P.rstd_ff + tok0 + tl, rs);
-        gst(P.Xout + el + c, c_ffg * xh + c_ffb);                 // the last layer's output is an fp32 tensor in every mode
+        ln_row(v, TP(eps), xh, rs);
+        ast<BF>(TP(xhat_ff), el + c, xh);
+        if (c == 0) gst(TP(rstd_ff) + tok0 + tl, rs);
+        gst(TP(Xout) + el + c, R.c_ffg * xh + R.c_ffb);           // the last layer's output is an fp32 tensor in every mode
     }
-    STAMP(15);
+    TSTAMP(15);
 }
-#undef PTYPE
+
+template <int DH, bool BF>
+__global__ void __launch_bounds__(256)
+top_fwd_kernel(const TopFwdP P_unused) {
+    constexpr unsigned KOFF = 0;
+    constexpr int TS = 64 * FS;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sX = sm;                       // x tile
+    float* sK = sm + TS;                  // K tile [token][feature]
+    float* sV = sm + 2 * TS;              // V tile [token][feature]
+    float* sPart = sm + 3 * TS;           // DFT partials [16][4][2][64] = 8192 floats
+    float* sTab = sPart + 8192;           // FUSED_MAX_CB * 128
+    float* sSpec = sTab + FUSED_MAX_CB * 128;   // FUSED_MAX_CB * 128
+    float* sVec = sSpec + FUSED_MAX_CB * 128;   // row vectors: [0]=q [64]=pd(h*64) [320]=ctx [384]=hmix [448]=g(256) [704]=dsp
+    int* sIds = reinterpret_cast<int*>(sVec + 768);
+    const int tid = threadIdx.x;
+    TSTAMP(0);
+    const int L = TP(L), cb = TP(cb);
+    const long tok0 = (long)blockIdx.x * L;
+    const DropSeed dseed = drop_seed(TP(drop_f));
+    TopFwdRegs<BF> R;
+    top_fwd_prefetch<BF, KOFF>(R);
+    {
+        const float* const X = TP(X);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+            f32x4 v = ald4<BF>(X, (tok0 + min(r, L - 1)) * 64 + c4);      // branch-free: rows past L re-read row L-1, zeroed
+            if (r >= L) v = f32x4{0, 0, 0, 0};
+            st4(sX + r * FS + c4, v);
+        }
+    }
+    if (tid < 64) sIds[tid] = tid < L ? gldi(TP(ids32) + (tok0 + tid)) : 0;
+    build_twiddle_table(TP(tw), L, cb, sTab);
+    lds_barrier();
+    TSTAMP(1);
+    top_fwd_rest<DH, BF, KOFF>(R, dseed, sX, sK, sV, sPart, sTab, sSpec, sVec, sIds);
+}
 
 static inline size_t top_fwd_smem_bytes() { return (size_t)(3 * 64 * FS + 8192 + 2 * FUSED_MAX_CB * 128 + 768 + 64) * 4; }
 
@@ -308,17 +343,19 @@ __device__ __forceinline__ float ln_row_bwd(float dy, float gamma, float xhat, f
     return rstd * (g - m1 - xhat * m2);
 }
 
-template <int DH, bool BF>
-__global__ void __launch_bounds__(256)
-top_bwd_kernel(const TopBwdP P) {
-#define PTYPE TopBwdP
-    constexpr int TS = 64 * FS;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* sX = sm;
-    float* sK = sm + TS;
-    float* sV = sm + 2 * TS;
-    float* sTab = sm + 3 * TS;                  // FUSED_MAX_CB * 128
-    float* sVec = sTab + FUSED_MAX_CB * 128;
+// The backward of the top block as a device function so that it can also run as the HEAD of the backward of the block
+// below it (fused_layer_bwd_kernel<.., HEADP = TopBwdP>): waves 0..3 of that kernel run it, its input gradient tile stays
+// in LDS (sDX) instead of a round trip through global memory, and waves 4..7 meanwhile stage the lower block's gelu'
+// tile.  Those waves keep the workgroup's barrier count in step: they execute TOP_BWD_BARRIERS barriers of their own --
+// EVERY lds_barrier() below is unconditional and top-level, and their number is that constant (tests/test_host_cpu.py
+// counts them in this source).  sTab is built by the caller.  sDX = null: dX goes to global memory (stand-alone kernel).
+#define TB(f) kernarg_field<decltype(TopBwdP::f)>(KOFF + (unsigned)offsetof(TopBwdP, f))
+#define BSTAMP(i) do { long long* st_ = TB(stamps); if (st_ && blockIdx.x == 0 && threadIdx.x == 0) st_[i] = clock64(); } while (0)
+static_assert(TOP_BWD_BARRIERS == 11, "barriers of top_bwd_body (fused_layer.h holds the constant)");
+
+template <int DH, bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, float* sK, float* sV, const float* sTab, float* sVec,
+                                             float* sDX) {
     float* sDT = sVec;            // 64   dT2 (grad of the dense_2 output)
     float* sDU = sVec + 64;       // 256  dU
     float* sRed = sVec + 320;     // 256  partial sums [4][64]
@@ -337,8 +374,8 @@ top_bwd_kernel(const TopBwdP P) {
     float* sSum = sVec + 2112;    // [2][4] sum_j ds, sum_j Drop(p) per head
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    STAMP(0);
-    const int L = P.L, Lp = P.Lp, heads = P.heads, cb = P.cb;
+    BSTAMP(0);
+    const int L = TB(L), Lp = TB(Lp), heads = TB(heads), cb = TB(cb);
     const int b = blockIdx.x, tl = L - 1;
     const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
 
@@ -346,48 +383,49 @@ top_bwd_kernel(const TopBwdP P) {
     // LayerNorm steps first, then the dense_2 columns of the first product; the x / k / v tiles (needed from the
     // attention step on) and the dense_1 columns are requested after the first barrier and land during dU / dH.
     const int c = lane;
-    const DropSeed dseed = drop_seed(KARG(TopBwdP, drop_f));
-    build_twiddle_table(P.tw, L, cb, sTab);
     // upstream gradient of the last row = sum of the logits backward's split-K slabs (<= 32): all loads issued back to
     // back (a rolled loop would wait for every load before the next one: ~0.14 us of L2 latency per slab)
     float dy = 0.f;
     {
-        const int ns = P.dh_nsplit;
+        const int ns = TB(dh_nsplit);
+        const float* const slabs = TB(dh_slabs);
+        const long stride = TB(dh_stride);
         float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sp = 0; sp < 32; ++sp) {
-            const float v = gld(P.dh_slabs + (long)min(sp, ns - 1) * P.dh_stride + (long)b * 64 + c);
+            const float v = gld(slabs + (long)min(sp, ns - 1) * stride + (long)b * 64 + c);
             part[sp & 3] += sp < ns ? v : 0.f;
         }
-        for (int sp = 32; sp < ns; ++sp) part[0] += gld(P.dh_slabs + (long)sp * P.dh_stride + (long)b * 64 + c);
+        for (int sp = 32; sp < ns; ++sp) part[0] += gld(slabs + (long)sp * stride + (long)b * 64 + c);
         dy = (part[0] + part[1]) + (part[2] + part[3]);
     }
-    const float xh_ff = ald<BF>(P.xhat_ff, el + c), g_ff = gld(P.ff_g + c), rs_ff = gld(P.rstd_ff + tok0 + tl);
-    const float xa = ald<BF>(P.xhat_a, el + c), xf = ald<BF>(P.xhat_f, el + c), g_a = gld(P.a_g + c), g_f = gld(P.f_g + c);
-    const float rs_a = gld(P.rstd_a + tok0 + tl), rs_f = gld(P.rstd_f + tok0 + tl);
-    const float bt = gld(P.sqrt_beta + c), low_l = gld(P.low + el + c), x_l = ald<BF>(P.X, el + c);
-    const float u_mine = ald<BF>(P.u, (tok0 + tl) * 256 + tid);
-    if (tid < 64) sQ[tid] = ald<BF>(P.q, el + tid);
+    const float xh_ff = ald<BF>(TB(xhat_ff), el + c), g_ff = gld(TB(ff_g) + c), rs_ff = gld(TB(rstd_ff) + tok0 + tl);
+    const float xa = ald<BF>(TB(xhat_a), el + c), xf = ald<BF>(TB(xhat_f), el + c), g_a = gld(TB(a_g) + c), g_f = gld(TB(f_g) + c);
+    const float rs_a = gld(TB(rstd_a) + tok0 + tl), rs_f = gld(TB(rstd_f) + tok0 + tl);
+    const float bt = gld(TB(sqrt_beta) + c), low_l = gld(TB(low) + el + c), x_l = ald<BF>(TB(X), el + c);
+    const float u_mine = ald<BF>(TB(u), (tok0 + tl) * 256 + tid);
+    if (tid < 64) sQ[tid] = ald<BF>(TB(q), el + tid);
     float w2c[64], w1c[64];
-    gemv_cols_load<64>(P.w2, 256, 0, tid, w2c);
+    gemv_cols_load<64>(TB(w2), 256, 0, tid, w2c);
     float dz_ff = 0.f;
     if (wave == 0) {            // FeedForward LayerNorm backward (row L-1)
         dz_ff = ln_row_bwd(dy, g_ff, xh_ff, rs_ff);
-        gst(P.pg_ff + (long)b * 64 + c, dy * xh_ff);
-        gst(P.pb_ff + (long)b * 64 + c, dy);
-        const float dt = dz_ff * drop_mult1(KARG(TopBwdP, drop_ff), dseed, (uint64_t)(el + c));
+        gst(TB(pg_ff) + (long)b * 64 + c, dy * xh_ff);
+        gst(TB(pb_ff) + (long)b * 64 + c, dy);
+        const float dt = dz_ff * drop_mult1(TB(drop_ff), dseed, (uint64_t)(el + c));
         sDT[c] = dt;
-        ast<BF>(P.dT, (long)b * 64 + c, dt);
+        ast<BF>(TB(dT), (long)b * 64 + c, dt);
     }
     lds_barrier();
-    STAMP(1);
-    gemv_cols_load<64>(P.w1, 64, 64 * wave, lane, w1c);
+    BSTAMP(1);
+    gemv_cols_load<64>(TB(w1), 64, 64 * wave, lane, w1c);
     f32x4 tx[4], tk[4], tv[4];
+    const float* const pX = TB(X); const float* const pK = TB(k); const float* const pV = TB(v);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
         const long et = (tok0 + min(r, L - 1)) * 64 + c4;            // branch-free: rows past L re-read row L-1, zeroed
-        tx[p] = ald4<BF>(P.X, et); tk[p] = ald4<BF>(P.k, et); tv[p] = ald4<BF>(P.v, et);
+        tx[p] = ald4<BF>(pX, et); tk[p] = ald4<BF>(pK, et); tv[p] = ald4<BF>(pV, et);
         if (r >= L) { tx[p] = f32x4{0, 0, 0, 0}; tk[p] = tx[p]; tv[p] = tx[p]; }
     }
 
@@ -395,17 +433,17 @@ top_bwd_kernel(const TopBwdP P) {
     {
         const float du = gemv_cols_dot<64>(w2c, sDT, 0) * gelu_grad_f(u_mine);
         sDU[tid] = du;
-        ast<BF>(P.dU, (long)b * 256 + tid, du);
+        ast<BF>(TB(dU), (long)b * 256 + tid, du);
     }
     lds_barrier();
-    STAMP(2);
+    BSTAMP(2);
     // ---- d(hmix) = dU . W1 + dz   (4 slices of 64 inner units)
     float woc[16], wqc[16], wkc[DH], wvc[DH];
-    gemv_cols_load<16>(P.wo, 64, 16 * wave, lane, woc);
-    gemv_cols_load<16>(P.wq, 64, 16 * wave, lane, wqc);
+    gemv_cols_load<16>(TB(wo), 64, 16 * wave, lane, woc);
+    gemv_cols_load<16>(TB(wq), 64, 16 * wave, lane, wqc);
     const bool hv = tid < heads * 64;             // thread (head = wave, i = lane) of the per-head vector products
-    gemv_cols_load<DH>(P.wk, 64, (hv ? wave : 0) * DH, lane, wkc);
-    gemv_cols_load<DH>(P.wv, 64, (hv ? wave : 0) * DH, lane, wvc);
+    gemv_cols_load<DH>(TB(wk), 64, (hv ? wave : 0) * DH, lane, wkc);
+    gemv_cols_load<DH>(TB(wv), 64, (hv ? wave : 0) * DH, lane, wvc);
     sRed[wave * 64 + lane] = gemv_cols_dot<64>(w1c, sDU, 64 * wave);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {                 // the tiles have landed by now
@@ -413,24 +451,25 @@ top_bwd_kernel(const TopBwdP P) {
         st4(sX + r * FS + c4, tx[p]); st4(sK + r * FS + c4, tk[p]); st4(sV + r * FS + c4, tv[p]);
     }
     lds_barrier();
-    STAMP(3);
+    BSTAMP(3);
     if (wave == 0) {
         const float dh = (sRed[c] + sRed[64 + c]) + (sRed[128 + c] + sRed[192 + c]) + dz_ff;
         // alpha mix + the two LayerNorm backwards (attention branch scaled by 1 - alpha, filter branch by alpha)
-        const float dya = P.oma * dh, dyf = P.alpha * dh;
+        const float oma = TB(oma), alpha = TB(alpha);
+        const float dya = oma * dh, dyf = alpha * dh;
         const float dza = ln_row_bwd(dya, g_a, xa, rs_a);
         const float dzf = ln_row_bwd(dyf, g_f, xf, rs_f);
-        gst(P.pg_a + (long)b * 64 + c, dya * xa); gst(P.pb_a + (long)b * 64 + c, dya);
-        gst(P.pg_f + (long)b * 64 + c, dyf * xf); gst(P.pb_f + (long)b * 64 + c, dyf);
-        const float dO = dza * drop_mult1(KARG(TopBwdP, drop_o), dseed, (uint64_t)(el + c));
-        const float dF = dzf * drop_mult1(KARG(TopBwdP, drop_f), dseed, (uint64_t)(el + c));
+        gst(TB(pg_a) + (long)b * 64 + c, dya * xa); gst(TB(pb_a) + (long)b * 64 + c, dya);
+        gst(TB(pg_f) + (long)b * 64 + c, dyf * xf); gst(TB(pb_f) + (long)b * 64 + c, dyf);
+        const float dO = dza * drop_mult1(TB(drop_o), dseed, (uint64_t)(el + c));
+        const float dF = dzf * drop_mult1(TB(drop_f), dseed, (uint64_t)(el + c));
         sDO[c] = dO;
-        ast<BF>(P.dO, (long)b * 64 + c, dO);
+        ast<BF>(TB(dO), (long)b * 64 + c, dO);
         const float b2 = bt * bt;
         sDF[c] = (1.0f - b2) * dF;
         sLast[c] = dza + dzf + b2 * dF;
         // d sqrt_beta: f = low + beta^2 (x - low)
-        gst(P.pbeta + (long)b * 64 + c, 2.0f * bt * dF * (x_l - low_l));
+        gst(TB(pbeta) + (long)b * 64 + c, 2.0f * bt * dF * (x_l - low_l));
         // column L-1 of the low-pass projector: P[j][L-1] = (1/L) sum_k w_k cos(2 pi k (j - (L-1)) / L)
         float pl = 0.f;
         if (c < L)
@@ -441,14 +480,14 @@ top_bwd_kernel(const TopBwdP P) {
         sPl[c] = pl / (float)L;
     }
     lds_barrier();
-    STAMP(4);
+    BSTAMP(4);
     // ---- dC = dO . Wo   (4 slices of 16 output features)
     sRed[wave * 64 + lane] = gemv_cols_dot<16>(woc, sDO, 16 * wave);
     lds_barrier();
-    STAMP(5);
+    BSTAMP(5);
     if (tid < 64) sDC[tid] = (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
     lds_barrier();
-    STAMP(6);
+    BSTAMP(6);
 
     // ---- attention backward of the last query: one wave per head, lane = key
     if (wave < heads) {
@@ -463,8 +502,8 @@ top_bwd_kernel(const TopBwdP P) {
                 dpd += vv.x * dv.x + vv.y * dv.y + vv.z * dv.z + vv.w * dv.w;
             }
             const long pe = (((long)b * heads + head) * L + tl) * Lp + key;
-            p = ald<BF>(P.probs, pe);
-            mp = drop_mult1(KARG(TopBwdP, drop_p), dseed, (uint64_t)pe);
+            p = ald<BF>(TB(probs), pe);
+            mp = drop_mult1(TB(drop_p), dseed, (uint64_t)pe);
         }
         const float dp = dpd * mp;
         const float delta = group_sum<64>(p * dp);
@@ -476,7 +515,7 @@ top_bwd_kernel(const TopBwdP P) {
         if (key == 0) { sSum[head] = s1; sSum[4 + head] = s2; }
     }
     lds_barrier();
-    STAMP(7);
+    BSTAMP(7);
     // ---- per-head vectors: dq, the weight-gradient operands of key / value, q_h Wk_h, dC_h Wv_h
     if (tid < 64) {
         const int c = tid, head = c / DH;
@@ -486,9 +525,9 @@ top_bwd_kernel(const TopBwdP P) {
         for (int j = 0; j < 64; ++j) a4[j & 3] += sDs[head * 64 + j] * sK[j * FS + c];
         acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         sDQ[c] = acc;
-        ast<BF>(P.dq, (long)b * 64 + c, acc);
-        gst(P.pbk + (long)b * 64 + c, sQ[c] * sSum[head]);
-        gst(P.pbv + (long)b * 64 + c, sDC[c] * sSum[4 + head]);
+        ast<BF>(TB(dq), (long)b * 64 + c, acc);
+        gst(TB(pbk) + (long)b * 64 + c, sQ[c] * sSum[head]);
+        gst(TB(pbv) + (long)b * 64 + c, sDC[c] * sSum[4 + head]);
     }
     if (hv) {
         const int head = wave, i = lane, o = tid;
@@ -503,34 +542,60 @@ top_bwd_kernel(const TopBwdP P) {
         rk += rk2; rv += rv2;
         const long e = ((long)b * heads + head) * 64 + i;
         const bool mine = i / DH == head;
-        ast<BF>(P.rk, e, rk); ast<BF>(P.rv, e, rv);
-        ast<BF>(P.ak, e, mine ? sQ[i] : 0.f); ast<BF>(P.av, e, mine ? sDC[i] : 0.f);
+        ast<BF>(TB(rk), e, rk); ast<BF>(TB(rv), e, rv);
+        ast<BF>(TB(ak), e, mine ? sQ[i] : 0.f); ast<BF>(TB(av), e, mine ? sDC[i] : 0.f);
         sQK[o] = gemv_cols_dot<DH>(wkc, sQ, head * DH);
         sCV[o] = gemv_cols_dot<DH>(wvc, sDC, head * DH);
     }
     lds_barrier();
-    STAMP(8);
+    BSTAMP(8);
     // dq . Wq joins the last row's extra gradient (4 slices of 16 features)
     sRed[wave * 64 + lane] = gemv_cols_dot<16>(wqc, sDQ, 16 * wave);
     lds_barrier();
-    STAMP(9);
+    BSTAMP(9);
     if (tid < 64) sLast[tid] += (sRed[tid] + sRed[64 + tid]) + (sRed[128 + tid] + sRed[192 + tid]);
     lds_barrier();
-    STAMP(10);
+    BSTAMP(10);
     // ---- dX, all rows
     {
         const int lr = tid >> 4, lc = (tid & 15) << 2;
         const f32x4 df = ld4(sDF + lc);
+        float* const pdX = sDX ? nullptr : TB(dX);
         for (int j = lr; j < L; j += 16) {
             f32x4 dx = df * sPl[j];
             for (int h = 0; h < heads; ++h)
                 dx += ld4(sQK + h * 64 + lc) * sDs[h * 64 + j] + ld4(sCV + h * 64 + lc) * sPd[h * 64 + j];
             if (j == tl) dx += ld4(sLast + lc);
-            ast4<BF>(P.dX, (tok0 + j) * 64 + lc, dx);
+            if (sDX) {
+                if constexpr (BF) {       // what the block below would read back from the bf16 gradient tensor
+                    const unsigned a = pk_bf16(dx.x, dx.y), c2 = pk_bf16(dx.z, dx.w);
+                    dx = f32x4{bf_lo(a), bf_hi(a), bf_lo(c2), bf_hi(c2)};
+                }
+                st4(sDX + j * FS + lc, dx);
+            } else ast4<BF>(pdX, (tok0 + j) * 64 + lc, dx);
         }
     }
-    STAMP(15);
+    lds_barrier();                // (counted in TOP_BWD_BARRIERS: the dX tile is complete)
+    BSTAMP(15);
 }
-#undef PTYPE
+
+template <int DH, bool BF>
+__global__ void __launch_bounds__(256)
+top_bwd_kernel(const TopBwdP P_unused) {
+    constexpr unsigned KOFF = 0;
+    constexpr int TS = 64 * FS;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sX = sm;
+    float* sK = sm + TS;
+    float* sV = sm + 2 * TS;
+    float* sTab = sm + 3 * TS;                  // FUSED_MAX_CB * 128
+    float* sVec = sTab + FUSED_MAX_CB * 128;
+    BSTAMP(0);
+    const DropSeed dseed = drop_seed(TB(drop_f));
+    build_twiddle_table(TB(tw), TB(L), TB(cb), sTab);
+    lds_barrier();
+    top_bwd_body<DH, BF, KOFF>(dseed, sX, sK, sV, sTab, sVec, nullptr);
+}
+
 
 static inline size_t top_bwd_smem_bytes() { return (size_t)(3 * 64 * FS + FUSED_MAX_CB * 128 + 2176) * 4; }

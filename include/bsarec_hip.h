@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define BSAREC_MAX_LAYERS 16
-#define BSAREC_ABI_VERSION 4
+#define BSAREC_ABI_VERSION 5
 
 /* Hyper-parameters the reference model reads from `args`
  * (src/utils.py:83-96; src/model/bsarec.py:71-88; src/model/_modules.py:79-87). */
@@ -59,6 +59,8 @@ typedef struct {
     int splits;         /* split-K slab slices of the weight-gradient products (0: 40) */
     int top_slabs;      /* slab slices of the one-row top block's weight-gradient products (0: 2) */
     int separate_embed; /* 1: the embedding front-end runs as its own kernel on the fused path too */
+    int separate_top;   /* 1: the one-row top block of the loss path runs as its own kernels instead of as the tail /
+                         * head of the launches of the block below it */
 } bsarec_config_t;
 
 /* The 19 tensors of one BSARecBlock, in state_dict order (+ the sibling model's filter weight)

@@ -57,6 +57,20 @@ def test_library_exports_every_shard_header_symbol():
         assert hasattr(lib, name), name
 
 
+def test_top_bwd_body_barrier_count_matches_the_constant():
+    """fused_layer_bwd_kernel<.., TopBwdP>: waves 4..7 execute TOP_BWD_BARRIERS barriers while waves 0..3 run top_bwd_body.
+    A mismatch would deadlock the workgroup, so the source is checked: every lds_barrier() of the body is a top-level
+    statement (4 spaces of indentation: not inside a branch or loop) and their number is the constant."""
+    top = open(os.path.join(ROOT, "bsarec_amd", "csrc", "fused_top.h")).read()
+    fused = open(os.path.join(ROOT, "bsarec_amd", "csrc", "fused_layer.h")).read()
+    const = int(re.search(r"constexpr int TOP_BWD_BARRIERS = (\d+);", fused).group(1))
+    body = top[top.index("void top_bwd_body("):top.index("top_bwd_kernel(const TopBwdP P_unused)")]
+    lines = [ln for ln in body.splitlines() if "lds_barrier();" in ln]
+    assert len(lines) == const, (len(lines), const)
+    assert all(re.match(r"^    lds_barrier\(\);", ln) for ln in lines), lines
+    assert "return;" not in body
+
+
 def test_workspace_query_and_shape_limits():
     import ctypes as C
     from bsarec_amd import _lib
