@@ -137,6 +137,7 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     const int wm = wave >> 1, wn = wave & 1, col = wn * 32 + l31;
     const int KH = (BF ? 8 : 4) * half;
     const int on = tid >> 2, osl = tid & 3;
+    TSTAMP(1);
 
     // ---- K, V projections of all rows (MFMA), spectrum of x (VALU)
     {
@@ -309,7 +310,6 @@ top_fwd_kernel(const TopFwdP P_unused) {
     if (tid < 64) sIds[tid] = tid < L ? gldi(TP(ids32) + (tok0 + tid)) : 0;
     build_twiddle_table(TP(tw), L, cb, sTab);
     lds_barrier();
-    TSTAMP(1);
     top_fwd_rest<DH, BF, KOFF>(R, dseed, sX, sK, sV, sPart, sTab, sSpec, sVec, sIds);
 }
 

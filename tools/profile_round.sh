@@ -22,5 +22,7 @@ python3 tools/timeline.py $(find $OUT/trace -name '*kernel_trace.csv' | head -1)
 find $OUT/trace -name '*.csv' ! -name '*stats*' -delete; find $OUT -size +8M -delete
 python3 tools/prof_summary.py $OUT/kernel_stats.csv 220 20
 cat $OUT/timeline.txt
+# the bench line's roofline.traffic comes from the PMC passes of THIS build (same library_sha16)
+if [ "$DT" = f32 ]; then cp $OUT/pmc.csv $R/profiles/r02_pmc_C1.csv; fi
 timeout -k 10 300 python3 bench.py --dtype $DT > $OUT/bench_line.json 2> $OUT/bench.err
 cat $OUT/bench_line.json
