@@ -177,6 +177,58 @@ class ShardedCatalogue:
             L.check(lib.bsarec_adam_apply(C.byref(ae), enc._state.data_ptr(), st), "bsarec_adam_apply")
         return self.loss[0]
 
+    # ---- evaluation ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def topk(self, input_ids, k: int = 20, seen=None):
+        """Full-catalogue top-k of this rank's B sequences over the SHARDED table (the reference's eval step,
+        src/trainers.py:118-141: scores of the last position against every item, items the user already interacted
+        with set to 0 -- not -inf --, top 20): local scores of all Bg sequences against the owned rows, local top-k,
+        all-gather of the W x k candidates, merge.  ``seen``: optional int64 [B, S] of item ids per sequence (padded with
+        -1).  Returns (scores [B, k], item ids [B, k])."""
+        import torch.distributed as dist
+        lib, enc, g = self.lib, self.encoder, self.group
+        B, Lq, d, W, Bg, n = self.B, self.Lq, self.d, self.W, self.Bg, self.n
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        assert tuple(ids.shape) == (B, Lq)
+        st = enc._stream()
+        self.px.barrier(st)
+        L.check(lib.bsarec_shard_gather_rows(ids.data_ptr(), n, C.byref(self._shards8), W, self.rows_per, self.V, d,
+                                             enc._arena.data_ptr(), self.local_ids.data_ptr(), st), "bsarec_shard_gather_rows")
+        was_training = enc.training
+        enc.eval()
+        plan = enc._run_forward(self.local_ids, train=False, new_step=False)
+        enc.train(was_training)
+        h_last = plan.view(L.BUF_LAYER_OUT, self.args.num_hidden_layers, (B, Lq, d))[:, Lq - 1, :].float().contiguous()
+        dist.all_gather(list(self.h_all.view(W, B, d).unbind(0)), h_last, group=g)
+        L.check(lib.bsarec_shard_logits(self.h_all.data_ptr(), d, Bg, self.E.data_ptr(), self.Vs, d, self.logits.data_ptr(),
+                                        self.ld, st), "bsarec_shard_logits")
+        scores = self.logits[:, :self.Vs]
+        if seen is not None:
+            sl = seen.to(device=self.device, dtype=torch.int64).contiguous()
+            S = sl.shape[1]
+            seen_all = torch.empty(W, B, S, dtype=torch.int64, device=self.device)
+            dist.all_gather(list(seen_all.unbind(0)), sl, group=g)
+            loc = seen_all.view(Bg, S) - self.lo
+            ok = (seen_all.view(Bg, S) >= 0) & (loc >= 0) & (loc < self.Vs)
+            rows = torch.arange(Bg, device=self.device).view(Bg, 1).expand(Bg, S)
+            scores[rows[ok], loc[ok]] = 0.0
+        kk = min(k, max(self.Vs, 1))
+        cand_v = torch.full((Bg, k), -float("inf"), device=self.device)
+        cand_i = torch.zeros(Bg, k, dtype=torch.int64, device=self.device)
+        if self.Vs:
+            v, i = torch.topk(scores, kk, dim=1)
+            cand_v[:, :kk], cand_i[:, :kk] = v, i + self.lo
+        all_v = torch.empty(W, Bg, k, device=self.device)
+        all_i = torch.empty(W, Bg, k, dtype=torch.int64, device=self.device)
+        dist.all_gather(list(all_v.unbind(0)), cand_v, group=g)
+        dist.all_gather(list(all_i.unbind(0)), cand_i, group=g)
+        mv = all_v.permute(1, 0, 2).reshape(Bg, W * k)
+        mi = all_i.permute(1, 0, 2).reshape(Bg, W * k)
+        top_v, sel = torch.topk(mv, k, dim=1)
+        top_i = torch.gather(mi, 1, sel)
+        r0 = self.rank * B
+        return top_v[r0:r0 + B].clone(), top_i[r0:r0 + B].clone()
+
     def close(self):
         torch.cuda.synchronize(self.device)
         torch.distributed.barrier(group=self.group)

@@ -135,6 +135,13 @@ def _batches(ns, steps, Bg):
     return out
 
 
+def _seen(ns, Bg):
+    g = torch.Generator(device="cpu").manual_seed(8)
+    seen = torch.randint(1, ns.item_size, (Bg, 30), generator=g)
+    seen[:, 25:] = -1
+    return seen
+
+
 def _full_model(ns):
     from bsarec_amd import BSARecModel
     torch.manual_seed(3)
@@ -155,6 +162,11 @@ def _worker(rank, world, port, kw, out_dir):
         for ids, ans in _batches(ns, 3, world * B):
             losses.append(float(sc.train_step(ids[rank * B:(rank + 1) * B], ans[rank * B:(rank + 1) * B])))
         assert not sc.px.timed_out()
+        # evaluation over the sharded table: top-20 with the "seen" items zeroed
+        ids, _ = _batches(ns, 1, world * B)[0]
+        seen = _seen(ns, world * B)
+        tv, ti = sc.topk(ids[rank * B:(rank + 1) * B], 20, seen[rank * B:(rank + 1) * B])
+        np.savez(os.path.join(out_dir, f"topk{rank}.npz"), v=tv.cpu().numpy(), i=ti.cpu().numpy())
         sd = {k: v.detach().cpu().numpy() for k, v in sc.full_state_dict().items()}
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.asarray(losses), **sd)
         sc.close()
@@ -162,21 +174,44 @@ def _worker(rank, world, port, kw, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(hidden_size=128, max_seq_length=64, num_attention_heads=4, item_size=1003, c=9)],
-                         ids=["fused_d64_L50", "generic_d128_L64"])
-def test_two_ranks_sharded_catalogue_equals_the_full_table_step(kw, tmp_path):
+@pytest.mark.parametrize("world,kw", [(2, dict()), (2, dict(hidden_size=128, max_seq_length=64, num_attention_heads=4, item_size=1003, c=9)),
+                                      (3, dict(item_size=302, batch_size=16))],
+                         ids=["W2_fused_d64_L50", "W2_generic_d128_L64", "W3_uneven_shards"])
+def test_ranks_sharded_catalogue_equals_the_full_table_step(world, kw, tmp_path):
+    """(W3: 302 rows over 3 ranks = 101 + 101 + 100 -- a shorter last shard.)"""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_worker, args=(2, port, kw, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in r0.files:
-        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)          # encoder replicas bit-identical; same gathered table
+    mp.spawn(_worker, args=(world, port, kw, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    for r in range(1, world):
+        rr = np.load(tmp_path / f"rank{r}.npz")
+        for k in r0.files:
+            np.testing.assert_array_equal(r0[k], rr[k], err_msg=k)      # encoder replicas bit-identical; same gathered table
     ns = _ns(**kw)
     model = _full_model(ns)
     model.configure_adam(lr=ns.lr, betas=(ns.adam_beta1, ns.adam_beta2), weight_decay=ns.weight_decay)
     model.train()
-    losses = [float(model.train_step(ids.cuda(), ans.cuda())) for ids, ans in _batches(ns, 3, 2 * ns.batch_size)]
+    losses = [float(model.train_step(ids.cuda(), ans.cuda())) for ids, ans in _batches(ns, 3, world * ns.batch_size)]
     np.testing.assert_allclose(r0["losses"], losses, atol=2e-4)
+    # the sharded top-20 (taken after the three steps) against the full table of the same run: the gathered table of rank 0
+    # IS the sharded model's table, so load it into a full model and score there
+    B = ns.batch_size
+    full = _full_model(ns)
+    full.load_state_dict({k: torch.from_numpy(r0[k]) for k in r0.files if k != "losses"})
+    full.eval()
+    ids, _ = _batches(ns, 1, world * B)[0]
+    seen = _seen(ns, world * B)
+    with torch.no_grad():
+        scores = full.full_logits(ids.cuda()).clone()
+    rows = torch.arange(world * B).view(-1, 1).expand_as(seen)
+    ok = seen >= 0
+    scores[rows[ok].cuda(), seen[ok].cuda()] = 0.0
+    want_v, want_i = torch.topk(scores, 20, dim=1)
+    for r in range(world):
+        t = np.load(tmp_path / f"topk{r}.npz")
+        wv, wi = want_v[r * B:(r + 1) * B].cpu().numpy(), want_i[r * B:(r + 1) * B].cpu().numpy()
+        np.testing.assert_allclose(t["v"], wv, rtol=1e-5, atol=1e-6)
+        assert (t["i"] == wi).mean() > 0.99                       # (equal scores may swap places)
     sd = model.state_dict()
     assert set(sd) == set(r0.files) - {"losses"}
     for k in sd:
