@@ -1315,7 +1315,7 @@ extern "C" int bsarec_train_step_indexed(bsarec_plan_t* p, const int64_t* table,
     // the extra block of the final gradient reduction closes the step: mean loss, Adam t and bias corrections, next
     // forward-step index, cursor += B
     const TickP tk = make_tick(p->state, 1, a->lr, a->beta1, a->beta2, p->loss_rows, p->cfg.batch, p->loss, cursor, p->cfg.batch, 1);
-    if (can_fuse_adam(*p, *a) && !p->cfg.separate_embed)       // 9 launches: the last one reduces and updates
+    if (can_fuse_adam(*p, *a) && !p->cfg.separate_embed)       // 7 launches: the last one reduces and updates
         return backward_impl(p, stream, tk, a);
     RET(backward_impl(p, stream, tk));
     return adam_launch(*a, p->state, s);
