@@ -116,6 +116,69 @@ def launch_ranks(a):
     return rc
 
 
+def p2p_probe_child():
+    """A throw-away process per rank (own process group on MASTER_PORT + 17) that exercises the peer-to-peer exchange on
+    THIS node's GPUs before the measuring processes commit to it: IPC export / import of the arenas and flags, the
+    barrier kernel, torch reads through every mapping (PeerExchange.create -> self_test) and one fused Adam step that
+    sums every rank's arena with the library's system-scope loads.  The peer-to-peer path reads other GPUs' memory from
+    kernels: were a mapping wrong the process would die of a memory fault -- here, not in the benchmark.  Exit 0 = usable."""
+    import ctypes as C
+    import torch
+    if os.environ.get("BSAREC_P2P_PROBE_FAIL") == "1":   # rehearsal of the fallback
+        return 5
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend = os.environ.get("BSAREC_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + 17)
+    if backend == "nccl":
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+    from bsarec_amd import _lib as Lb
+    from bsarec_amd.dp import PeerExchange
+    n = 322368                                          # the C1 arena
+    px = PeerExchange.create(n, torch.distributed.group.WORLD, dev)
+    if px is None:
+        return 3
+    px.arenas[0].fill_(float(rank + 1))
+    st = torch.cuda.current_stream().cuda_stream
+    px.barrier(st)
+    w, m, v = (torch.zeros(n, device=dev) for _ in range(3))
+    state = torch.zeros(8, dtype=torch.int64, device=dev)
+    ad = Lb.Adam(w.data_ptr(), px.arenas[0].data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0 / world, None, 0)
+    ad.n_grad_srcs = world
+    for i, q in enumerate(px.grad_srcs(0)):
+        ad.grad_srcs[i] = q
+    Lb.check(Lb.load().bsarec_adam_step(C.byref(ad), state.data_ptr(), st), "bsarec_adam_step")
+    px.barrier(st)
+    torch.cuda.synchronize()
+    g = (world + 1) / 2.0                               # mean over ranks of (rank + 1)
+    ok = bool(torch.allclose(m, torch.full_like(m, 0.1 * g), rtol=1e-5)) and bool(torch.allclose(w, torch.full_like(w, -1e-3), rtol=1e-3))
+    ok = ok and not px.timed_out()
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    px.close()
+    torch.distributed.destroy_process_group()
+    return 0 if flag.item() == 1.0 else 4
+
+
+def p2p_probe(a, world, backend):
+    """Run p2p_probe_child in a child of this (not yet GPU-touching) rank; True if it exited 0 in time."""
+    env = dict(os.environ, BSAREC_P2P_PROBE_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=sys.stderr)
+        try:
+            return p.wait(timeout=float(os.environ.get("BSAREC_P2P_PROBE_TIMEOUT", "240"))) == 0
+        except subprocess.TimeoutExpired:
+            p.kill()                                    # the exact PID started above
+            return False
+    except OSError:
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,6 +208,14 @@ def main():
         sys.exit(launch_ranks(a))                        # before anything here touches a GPU
     if world != a.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {a.gpus}")
+    if os.environ.get("BSAREC_P2P_PROBE_CHILD") == "1":
+        sys.exit(p2p_probe_child())
+    # N > 1 with the default exchange: try the peer-to-peer path in a throw-away child process first (before THIS process
+    # touches a GPU); a crash or a hang there costs the probe, not the benchmark, which then runs on RCCL
+    probe_ok = None
+    if world > 1 and a.exchange == "auto" and (os.environ.get("BSAREC_DIST_BACKEND", "nccl") == "nccl" or
+                                              os.environ.get("BSAREC_P2P_PROBE") == "1"):
+        probe_ok = p2p_probe(a, world, os.environ.get("BSAREC_DIST_BACKEND", "nccl"))
 
     import numpy as np
     import torch
@@ -187,8 +258,17 @@ def main():
     seqs = D.synth_ml1m_like(seed=42, n_items=a.item_size - 1)
     users, inputs, answers = D.train_table(seqs, a.seq_len)
     batches = D.DeviceBatches(users, inputs, answers, a.batch, dev, shuffle=True, seed=42, rank=rank, world=world)
+    exchange = a.exchange
+    if probe_ok is not None:                            # every rank's probe must have passed
+        f = torch.tensor([1.0 if probe_ok else 0.0], device=dev)
+        torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN, group=pg)
+        probe_ok = bool(f.item() == 1.0)
+        if not probe_ok:
+            exchange = "rccl"
+            if rank == 0:
+                print("bench: the peer-to-peer probe failed on some rank -- gradient exchange through RCCL", file=sys.stderr)
     trainer = Trainer(model, batches, None, None, margs, None, use_graph=not a.no_graph, process_group=pg,
-                      exchange=a.exchange)
+                      exchange=exchange)
     use_graph = trainer.use_graph
 
     # steps come straight off the device-resident table: per step ONE C call (gather + fwd + CE + bwd + Adam),
@@ -292,6 +372,9 @@ def main():
         out["allreduce_us"] = round(ev0.elapsed_time(ev1) * 1e3 / 50, 2)
         out["allreduce_bytes"] = int(g.numel() * 4)
         out["exchange"] = trainer.exchange_report()
+        if probe_ok is not None:
+            out["exchange"]["p2p_probe"] = "passed (separate process per rank, before the run)" if probe_ok else \
+                "failed: this run exchanges gradients through RCCL"
         # the replicas must still be bit-identical after the timed steps (only gradients are exchanged)
         cs = model._arena.double().sum().view(1)
         lo, hi = cs.clone(), cs.clone()
