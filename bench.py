@@ -168,6 +168,10 @@ def p2p_probe(a, world, backend):
     """Run p2p_probe_child in a child of this (not yet GPU-touching) rank; True if it exited 0 in time."""
     env = dict(os.environ, BSAREC_P2P_PROBE_CHILD="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # under torch.distributed.run the agent hosts the rendezvous store of the MAIN group; the probe group (MASTER_PORT + 17)
+    # must host its own (its rank 0), so it must not be told to look for an agent store
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        env.pop(k)
     try:
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=sys.stderr)
         try:
