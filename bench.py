@@ -298,11 +298,17 @@ def main():
             self.cursor.zero_()
             self.pos = 0
 
-        def step(self):
-            if self.pos + B > self.n_local:
-                self.new_epoch()
-            self.pos += B
-            return self.tr.indexed_step(self.bt, self.perm_buf, self.cursor, None)
+        def run(self, nsteps):
+            """Exactly ``nsteps`` optimisation steps (groups of Trainer.steps_per_graph of them replay as one graph launch)."""
+            loss = None
+            while nsteps > 0:
+                if self.pos + B > self.n_local:
+                    self.new_epoch()
+                k = min(nsteps, (self.n_local - self.pos) // B)
+                loss = self.tr.indexed_steps(self.bt, self.perm_buf, self.cursor, None, k)
+                self.pos += k * B
+                nsteps -= k
+            return loss
 
     feed = Feed(trainer, batches)
 
@@ -322,12 +328,10 @@ def main():
         torch.cuda.synchronize()
 
     def timed(fd, steps, warmup):
-        for _ in range(max(warmup, 1)):
-            loss = fd.step()
+        loss = fd.run(max(warmup, 1))
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = fd.step()
+        loss = fd.run(steps)
         barrier()
         dt = time.perf_counter() - t0
         return dt, loss
@@ -377,7 +381,7 @@ def main():
                                f"{a.layers} BSARec layers, {a.heads} heads, c=3 alpha=0.9 dropout=0.5, Adam lr=1e-3; "
                                "fwd + full-catalogue CE + bwd + Adam per step",
                    "batch_per_gpu": a.batch, "global_batch": a.batch * world, "seq_len": a.seq_len,
-                   "parallelism": f"dp{world}", "launch": ("hipGraph replay" if use_graph else "eager") +
+                   "parallelism": f"dp{world}", "launch": ((f"hipGraph replay, {trainer.steps_per_graph} steps per graph launch" if trainer.steps_per_graph > 1 else "hipGraph replay") if use_graph else "eager") +
                              (f"; data-parallel exchange: {trainer.exchange_desc()}" if pg is not None else ""),
                    "final_loss": round(final_loss, 4)},
     }

@@ -64,6 +64,10 @@ class Trainer:
     # ---- data-parallel gradient exchange (bsarec_amd/dp.py) ------------------------------------------
     def _setup_exchange(self):
         self._px, self._side, self._b1_done, self._nsteps = None, None, None, 0
+        # indexed_steps(): this many consecutive steps replay as ONE graph launch (env BSAREC_STEPS_PER_GRAPH; 1 = a graph per step)
+        spg = os.environ.get("BSAREC_STEPS_PER_GRAPH", "")
+        self.steps_per_graph = int(spg) if spg.isdigit() and int(spg) >= 1 else 16      # measured 1 / 4 / 8 / 16: 0.1793 / 0.1766 / 0.1764 / 0.1758 ms per step
+        self._last_multi = 1
         if not self.dp:
             self.exchange = "none"
             return
@@ -215,7 +219,8 @@ class Trainer:
         graph.replay()
         return loss
 
-    def indexed_step(self, dl: DeviceBatches, pbuf: torch.Tensor, cursor: torch.Tensor, loss_sum: Optional[torch.Tensor]):
+    def indexed_step(self, dl: DeviceBatches, pbuf: torch.Tensor, cursor: torch.Tensor, loss_sum: Optional[torch.Tensor],
+                     multi: int = 1):
         """One optimisation step straight off the device-resident sample table (the batch at ``cursor`` in the
         permutation ``pbuf``; the cursor advances on the device).  Single GPU: ONE captured graph (gather + forward +
         CE + backward + Adam).  Data parallel: graph A (gather + forward + CE + backward), the summing all-reduce of the
@@ -226,10 +231,12 @@ class Trainer:
         p2p, bucketed = self.exchange == "p2p", self.exchange == "rccl_bucketed"
         parity = (self._nsteps & 1) if p2p else 0
         self._nsteps += 1
-        key = ("indexed", B, pbuf.data_ptr(), pbuf.shape[0], cursor.data_ptr(), None if loss_sum is None else loss_sum.data_ptr(), parity)
+        self._last_multi = 1
+        base_key = (B, pbuf.data_ptr(), pbuf.shape[0], cursor.data_ptr(), None if loss_sum is None else loss_sum.data_ptr())
+        key = ("indexed",) + base_key + (parity,)
         st = lambda: torch.cuda.current_stream(self.device).cuda_stream
 
-        def grad_part():
+        def grad_part(parity=parity):
             if not self.dp:
                 loss = m.train_step_indexed(dl.inputs, dl.answers, pbuf, cursor, B)
             else:
@@ -250,7 +257,7 @@ class Trainer:
             else:
                 allreduce_sum_(m._garena, self.pg, force=True)
 
-        def adam_part():
+        def adam_part(parity=parity):
             # t / bias corrections: advanced by the grad step
             m.adam_step(grad_scale=1.0 / self.world, tick=False, grad_srcs=self._px.grad_srcs(parity) if p2p else None)
 
@@ -305,11 +312,49 @@ class Trainer:
             return loss
         ga, gb, gloss = g
         m._fresh_step_counter(m._plan(B, parity))             # a begin-style step (eager tail batch) came before: new masks
+        # k consecutive steps as ONE graph launch (the cursor, the dropout step and Adam's t advance on the device, so the
+        # k copies of the step chain by themselves): one graph start / end per k steps instead of per step.  Used by
+        # indexed_steps() once the per-step graphs exist (both parities under p2p); not for the two-graph form.
+        if multi > 1 and gb is None:
+            mkey = ("indexed_multi",) + base_key + (multi, parity)
+            mg = self._graphs.get(mkey)
+            if mg is None and not (p2p and ("indexed",) + base_key + (1 - parity,) not in self._graphs):
+                set_hook(bucketed and self.dp_graph == "one")         # (else: the other parity's plan / graph has not run yet)
+                gm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gm):
+                    for i in range(multi):
+                        q = ((parity + i) & 1) if p2p else 0
+                        mloss = grad_part(q)
+                        if self.dp:
+                            exchange(bucketed)
+                            adam_part(q)
+                mg = self._graphs[mkey] = (gm, mloss)
+            if mg is not None:
+                mg[0].replay()
+                self._nsteps += multi - 1
+                self._last_multi = multi
+                return mg[1]
         ga.replay()
         if gb is not None:
             exchange(False)
             gb.replay()
         return gloss
+
+    def indexed_steps(self, dl: DeviceBatches, pbuf: torch.Tensor, cursor: torch.Tensor, loss_sum: Optional[torch.Tensor], n: int):
+        """``n`` consecutive indexed steps (the caller guarantees n full batches are left in ``pbuf`` behind the cursor).
+        Groups of ``steps_per_graph`` steps replay as one graph launch where the step is a single graph; returns the loss
+        of the last step (a view of the device scalar)."""
+        k = self.steps_per_graph if self.use_graph else 1
+        loss = None
+        while n > 0:
+            p2p = self.exchange == "p2p"
+            if k > 1 and n >= k:
+                loss = self.indexed_step(dl, pbuf, cursor, loss_sum, multi=k)
+                n -= self._last_multi
+            else:
+                loss = self.indexed_step(dl, pbuf, cursor, loss_sum)
+                n -= 1
+        return loss
 
     def _epoch_indexed(self, dl: DeviceBatches):
         """One epoch off the device-resident sample table; no per-step host tensor work."""
@@ -326,8 +371,7 @@ class Trainer:
         pbuf = self._perm_buf[:n]
         self._cursor.zero_()
         self._loss_sum.zero_()
-        for _ in range(nfull):
-            self.indexed_step(dl, pbuf, self._cursor, self._loss_sum)
+        self.indexed_steps(dl, pbuf, self._cursor, self._loss_sum, nfull)
         nb = nfull
         if tail:                                            # short last batch (single GPU only): its own plan, eager
             idx = perm[nfull * B:]
