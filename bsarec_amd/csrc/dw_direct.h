@@ -82,18 +82,18 @@ __device__ __forceinline__ void dw_issue(DwStage<BF>& st, __amdgpu_buffer_rsrc_t
     }
 }
 
-template <bool GELU, bool MASK, bool BF>
+template <bool GELU, bool MASK, bool BF, int STAGES>
 __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob, int soa, int sob,
                                         int rowa, int rowb, int nkb, int crow, int kend, f32x16 (&acc)[2][2], f32x2& bs) {
-    DwStage<BF> st[DW_STAGES];
+    DwStage<BF> st[STAGES];
 #pragma unroll
-    for (int u = 0; u < DW_STAGES; ++u) {
+    for (int u = 0; u < STAGES; ++u) {
         dw_issue(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
         soa += 8 * rowa; sob += 8 * rowb;
     }
-    for (int kb = 0; kb < nkb; kb += DW_STAGES) {       // nkb is a multiple of DW_STAGES (rows past kend count as zero)
+    for (int kb = 0; kb < nkb; kb += STAGES) {          // nkb is a multiple of STAGES (rows past kend count as zero)
 #pragma unroll
-        for (int u = 0; u < DW_STAGES; ++u) {
+        for (int u = 0; u < STAGES; ++u) {
             DwStage<BF>& cur = st[u];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -125,13 +125,16 @@ __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buff
 
 // One workgroup = one (problem, 64 x 64 tile, slab slice): its 4 waves take the 4 quarters of the slice, meet in LDS,
 // wave 0 writes the slab.
+// STAGES = k-blocks in flight per wave = the granule the wave's k range is rounded up to: 5 for the block weight
+// gradients (10 k-blocks per wave at C1), 4 for the logits backward (8 resp. 16 k-blocks per wave: no padding MFMAs).
+template <int STAGES = DW_STAGES>
 __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, int slab, float (*red)[66][64]) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
     // this wave's quarter of the slab slice
     const int sub = Q.kchunk >> 2;                                       // multiple of 8
     const int kbeg = slab * Q.kchunk + wv * sub, kend = min(Q.K, kbeg + sub);
-    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * DW_STAGES - 1) / (8 * DW_STAGES)) * DW_STAGES : 0;
+    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * STAGES - 1) / (8 * STAGES)) * STAGES : 0;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -155,11 +158,11 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
         const bool full = kbeg + 8 * nkb <= kend;
 #define DW_RUN(BFV) \
         if (Q.gelu) { \
-            if (full) dw_loop<true, false, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
-            else dw_loop<true, true, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
+            if (full) dw_loop<true, false, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
+            else dw_loop<true, true, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
         } else { \
-            if (full) dw_loop<false, false, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
-            else dw_loop<false, true, BFV>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
+            if (full) dw_loop<false, false, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
+            else dw_loop<false, true, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
         }
         if (Q.bf16) { DW_RUN(true) } else { DW_RUN(false) }
 #undef DW_RUN
@@ -256,6 +259,7 @@ struct DhP {
     float* slab;                       // [nsplit][B][64]
 };
 
+template <int STAGES = DW_STAGES>
 __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
@@ -263,7 +267,7 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
     const int unit = wg * 4 + wv, mt = unit % mtiles, split = unit / mtiles;
     if (split >= G.nsplit) return;
     const int kbeg = split * G.kchunk, kend = min(G.V, kbeg + G.kchunk);
-    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * DW_STAGES - 1) / (8 * DW_STAGES)) * DW_STAGES : 0;
+    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * STAGES - 1) / (8 * STAGES)) * STAGES : 0;
     const int m = min(32 * mt + l31, G.B - 1);                       // rows past B re-read the last row; never stored
     f32x16 acc0, acc1;
 #pragma unroll
@@ -274,7 +278,7 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)G.E, 0, (int)((long)G.V * 256), 0x00020000);
         const int voa = (int)((long)m * G.lda * 4) + 16 * half, vob = 4 * half * 256 + 8 * l31;      // bytes
         int soa = kbeg * 4, sob = kbeg * 256, ccol = kbeg + 4 * half;
-        f32x4 sa[DW_STAGES]; f32x2 sb[DW_STAGES][4];
+        f32x4 sa[STAGES]; f32x2 sb[STAGES][4];
         auto issue = [&](int u) {
             sa[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa, soa, 0));
 #pragma unroll
@@ -282,10 +286,10 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
             soa += 32; sob += 8 * 256;
         };
 #pragma unroll
-        for (int u = 0; u < DW_STAGES; ++u) issue(u);
-        for (int kb = 0; kb < nkb; kb += DW_STAGES) {
+        for (int u = 0; u < STAGES; ++u) issue(u);
+        for (int kb = 0; kb < nkb; kb += STAGES) {
 #pragma unroll
-            for (int u = 0; u < DW_STAGES; ++u) {
+            for (int u = 0; u < STAGES; ++u) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float a = ccol + s < kend ? sa[u][s] : 0.f;      // columns past the slice (other splits' / next row's data)
@@ -314,7 +318,7 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
 __global__ void __launch_bounds__(256)
 logits_bwd_direct_kernel(const DwProblem Q, int tiles, const DhP H) {
     __shared__ __attribute__((aligned(16))) float red[3][66][64];
-    if ((int)blockIdx.x < tiles) dw_wg_body(Q, 64 * (int)blockIdx.x, 0, 0, red);
-    else dh_wave_body(H, (int)blockIdx.x - tiles);
+    if ((int)blockIdx.x < tiles) dw_wg_body<4>(Q, 64 * (int)blockIdx.x, 0, 0, red);
+    else dh_wave_body<4>(H, (int)blockIdx.x - tiles);
 }
 
