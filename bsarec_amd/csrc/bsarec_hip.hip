@@ -28,7 +28,7 @@ static thread_local bool g_dry = false;
 // Every option lives in bsarec_config_t and belongs to the plan (no process-wide knobs).  Defaults of the 0 values:
 //   top_slabs 2  (slab slices of the pruned top block's weight-gradient products, K = B or B*h rows only; measured
 //                 1/2/4/8 slabs: 0.2115 / 0.2095 / 0.2122 / 0.2130 ms per step)
-//   splits    40 (slab slices of the full-block weight-gradient products)
+//   splits    32 at the fused shape, 40 elsewhere (slab slices of the full-block weight-gradient products)
 struct bsarec_plan;
 static thread_local bsarec_plan* t_plan = nullptr;   // plan of the C call this thread is inside (ProfScope, stamps)
 
@@ -207,7 +207,10 @@ static void derive(bsarec_plan& p) {
     p.rows_pb = p.fused ? c.seq_len : 64;
     // split-K over tokens for the weight-gradient products: ~40 slab slices, 32-aligned chunks (the direct kernel of
     // the fused shape cuts every slice into 4 more quarters inside a workgroup)
-    const int want_splits = c.splits > 0 ? c.splits : 40;
+    // fused shape, C1 (12 weight-gradient units): 32 slices = 384 workgroups leave 128 of the kernel's 512 slots to the
+    // embedding scatter blocks from the first cycle (measured with exact k-block counts, 24 / 28 / 32 / 40 slices:
+    // 0.1722 / 0.1706 / 0.1694 / 0.1745 ms per step)
+    const int want_splits = c.splits > 0 ? c.splits : (p.fused ? 32 : 40);
     p.top_slabs = c.top_slabs > 0 ? c.top_slabs : 2;
     p.embed_in_block = !c.separate_embed || p.bf;     // bf16 storage: X[0] is written by the block kernel only
     p.direct_dw = !c.dw_tiled && (long)p.T * 4 * c.hidden * 4 < (1L << 31);      // its operands sit behind 32-bit buffer offsets

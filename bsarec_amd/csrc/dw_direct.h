@@ -91,9 +91,10 @@ __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buff
         dw_issue(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
         soa += 8 * rowa; sob += 8 * rowb;
     }
-    for (int kb = 0; kb < nkb; kb += STAGES) {          // nkb is a multiple of STAGES (rows past kend count as zero)
+    for (int kb = 0; kb < nkb; kb += STAGES) {          // the last group may be short (wave-uniform test per stage)
 #pragma unroll
         for (int u = 0; u < STAGES; ++u) {
+            if (kb + u >= nkb) break;
             DwStage<BF>& cur = st[u];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -134,7 +135,7 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
     // this wave's quarter of the slab slice
     const int sub = Q.kchunk >> 2;                                       // multiple of 8
     const int kbeg = slab * Q.kchunk + wv * sub, kend = min(Q.K, kbeg + sub);
-    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * STAGES - 1) / (8 * STAGES)) * STAGES : 0;
+    const int nkb = kend > kbeg ? (kend - kbeg + 7) >> 3 : 0;           // k-blocks of 8 token rows (rows past kend count as zero)
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -155,7 +156,7 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
         const int voa = 4 * half * rowa + (m0 + 2 * l31) * esz, vob = 4 * half * rowb + (n0 + 2 * l31) * esz;
         const int soa = kbeg * rowa, sob = kbeg * rowb;
         const int crow = kbeg + 4 * half;
-        const bool full = kbeg + 8 * nkb <= kend;
+        const bool full = kbeg + 8 * nkb <= kend;                            // no partial last k-block: the unmasked loop
 #define DW_RUN(BFV) \
         if (Q.gelu) { \
             if (full) dw_loop<true, false, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
@@ -267,7 +268,7 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
     const int unit = wg * 4 + wv, mt = unit % mtiles, split = unit / mtiles;
     if (split >= G.nsplit) return;
     const int kbeg = split * G.kchunk, kend = min(G.V, kbeg + G.kchunk);
-    const int nkb = kend > kbeg ? ((kend - kbeg + 8 * STAGES - 1) / (8 * STAGES)) * STAGES : 0;
+    const int nkb = kend > kbeg ? (kend - kbeg + 7) >> 3 : 0;
     const int m = min(32 * mt + l31, G.B - 1);                       // rows past B re-read the last row; never stored
     f32x16 acc0, acc1;
 #pragma unroll
@@ -290,6 +291,7 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
         for (int kb = 0; kb < nkb; kb += STAGES) {
 #pragma unroll
             for (int u = 0; u < STAGES; ++u) {
+                if (kb + u >= nkb) break;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float a = ccol + s < kend ? sa[u][s] : 0.f;      // columns past the slice (other splits' / next row's data)
