@@ -46,12 +46,15 @@ def _worker(rank, world, port, graph, exchange, out_dir):
         dl = D.DeviceBatches(u, x, a_, 64, "cuda", shuffle=True, seed=11, rank=rank, world=world)
         tr = Trainer(model, dl, None, None, _ns(), None, use_graph=graph, process_group=dist.group.WORLD, exchange=exchange)
         assert tr.exchange == exchange, (tr.exchange, exchange)       # no silent fallback in this test
+        tr.steps_per_graph = 4                   # 8 steps per epoch and rank: groups of 4 replay as ONE graph launch (p2p)
         if exchange != "p2p":
             tr.dp_graph = "two"                  # gloo's all-reduce cannot be captured: grad graph + eager exchange + Adam graph
         losses = [float(tr.train(e)["rec_loss"]) for e in range(2)]
         if exchange == "p2p":
             assert not tr._px.timed_out()
             assert tr.dp_graph == "one" or not graph
+            if graph:
+                assert any(k[0] == "indexed_multi" for k in tr._graphs if isinstance(k, tuple)), "multi-step graph not exercised"
         sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.asarray(losses), **sd)
     finally:

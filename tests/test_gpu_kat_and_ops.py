@@ -152,8 +152,8 @@ def test_full_size_properties_batch_equivariance_and_normalisation():
 
 
 def test_trainer_loop_graph_replay_equals_eager_and_learns():
-    """Trainer.iteration(train=True): hipGraph replay and eager launches give the same parameters bit
-    for bit (same Philox stream, deterministic reductions except the atomic scatter -> allow 1e-6), the
+    """Trainer.iteration(train=True): hipGraph replay (incl. several steps per graph launch) and eager launches give the
+    same parameters bit for bit (same Philox stream, deterministic reductions except the atomic scatter -> allow 1e-6), the
     short last batch goes through its own plan, and the loss goes down."""
     from bsarec_amd import BSARecModel, data as D
     from bsarec_amd.trainer import Trainer
@@ -167,7 +167,10 @@ def test_trainer_loop_graph_replay_equals_eager_and_learns():
         model.set_seed(5)
         dl = D.DeviceBatches(u, x, a, 256, "cuda", shuffle=True, seed=11)
         tr = Trainer(model, dl, None, None, ns(item_size=301), None, use_graph=(mode == "graph"))
+        tr.steps_per_graph = 2                  # 4 full batches per epoch: pairs of steps replay as ONE graph launch
         losses = [float(tr.train(e)["rec_loss"]) for e in range(3)]
+        if mode == "graph":
+            assert any(k[0] == "indexed_multi" for k in tr._graphs if isinstance(k, tuple)), "multi-step graph not exercised"
         res[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
         assert losses[-1] < losses[0]
     # the embedding scatter uses float atomics (arrival order varies run to run, last-bit differences in dE), and Adam
