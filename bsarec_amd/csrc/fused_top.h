@@ -186,10 +186,12 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     }
     lds_barrier();
     TSTAMP(2);
-    // feed-forward weight rows: requested here (nothing below loads from global memory until they are used)
+    // feed-forward weight rows.  Lane n reads ITS row, 32-64 cache lines per wave instruction: the ISSUE of the 32 loads
+    // costs ~7 k cycles of the CU's address path and the wave cannot move on before its loads are issued.  dense_1's rows
+    // are requested here; dense_2's (needed two steps later) by waves 1..3 while wave 0 runs the LayerNorm + mix row
+    // alone, and by wave 0 right after it -- in the shadow of steps that leave the address path idle.
     f32x4 w1r[16], w2r[16];
     gemv_rows_load<64, 1>(TP(w1), 64, tid, 0, w1r);
-    gemv_rows_load<256, 4>(TP(w2), 256, on, osl, w2r);
 
     // ---- attention row of the last query: one wave per head, lane = key        src/model/_modules.py:118-135
     if (wave < heads) {
@@ -235,6 +237,7 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     }
     lds_barrier();
     TSTAMP(5);
+    if (wave != 0) gemv_rows_load<256, 4>(TP(w2), 256, on, osl, w2r);
     if (wave == 0) {
         const int c = lane;
         const float v = sG[c] * drop_mult1(TP(drop_o), dseed, (uint64_t)(el + c)) + sX[tl * FS + c];
@@ -246,6 +249,7 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
         const float hm = TP(alpha) * sDsp[c] + TP(oma) * a;
         sHm[c] = hm;
         ast<BF>(TP(hmix), el + c, hm);
+        gemv_rows_load<256, 4>(TP(w2), 256, on, osl, w2r);
     }
     lds_barrier();
     TSTAMP(6);
