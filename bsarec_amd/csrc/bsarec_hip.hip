@@ -205,7 +205,7 @@ static void derive(bsarec_plan& p) {
     // LayerNorm gamma/beta partials: one row per 64-token block, or one per sequence on the fused path
     p.nblk = p.fused ? c.batch : cdiv(p.T, 64);
     p.rows_pb = p.fused ? c.seq_len : 64;
-    // split-K over tokens for the weight-gradient products: ~40 slab slices, 32-aligned chunks (the direct kernel of
+    // split-K over tokens for the weight-gradient products: 32 / 40 slab slices (below), 32-aligned chunks (the direct kernel of
     // the fused shape cuts every slice into 4 more quarters inside a workgroup)
     // fused shape, C1 (12 weight-gradient units): 32 slices = 384 workgroups leave 128 of the kernel's 512 slots to the
     // embedding scatter blocks from the first cycle (measured with exact k-block counts, 24 / 28 / 32 / 40 slices:

@@ -47,7 +47,7 @@ struct DwP {
     // Units [0, nsmall) belong to the tiny problems of the pruned top block (K = B or B*h rows, `small_slabs` slab
     // slices each): they take the LAST nsmall * small_slabs workgroups of the grid on their own -- no empty
     // workgroups; the big problems' 8 * ceil(nslab / 8) * (nunits - nsmall) workgroups come first so that all of them
-    // are resident from the start (480 of the 512 slots at C1), the small ones fill the rest and finish early.
+    // are resident from the start (384 of the 512 slots at C1), the small ones fill the rest and finish early.
     int nsmall, small_slabs;
 };
 
