@@ -160,7 +160,8 @@ def test_eval_mode_ignores_dropout_and_is_deterministic():
     assert not torch.equal(c, d)                         # new step -> new masks
 
 
-@pytest.mark.parametrize("heads,L,B", [(1, 50, 9), (2, 50, 33), (4, 50, 5), (2, 64, 3), (2, 20, 7), (4, 33, 6)])
+@pytest.mark.parametrize("heads,L,B", [(1, 50, 9), (2, 50, 33), (4, 50, 5), (2, 64, 3), (2, 20, 7), (4, 33, 6), (2, 8, 4), (1, 5, 3),
+                                       (2, 2, 6)])
 @pytest.mark.parametrize("fused", [2, 1, 0])
 def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
     """hidden = 64, L <= 64 takes the fused per-sequence BSARecBlock kernels (fused = 2: with the top block of the
@@ -202,7 +203,12 @@ def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
             assert rel_l2(g, r) <= 2e-5, (l, rel_l2(g, r))
             assert np.abs(g - r).max() <= 1e-3, (l, np.abs(g - r).max())
         assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss)
-        check_grads(model, G, tol=2e-4)
+        skip = ()
+        if 5 // 2 + 1 >= L // 2 + 1:            # the "low-pass" keeps the whole spectrum (L = 2, 5): x - low is rounding noise and
+            skip = tuple(k for k in G if k.endswith("sqrt_beta"))        # d sqrt_beta, a sum of such terms, is zero up to noise
+            for k in skip:
+                assert np.abs(model.grad_views()[k].cpu().numpy()).max() <= 1e-5 and np.abs(G[k]).max() <= 1e-5, k
+        check_grads(model, G, tol=2e-4, skip=skip)
     finally:
         Lb.set_default_options(no_fused=0, no_prune_top=0)
 
