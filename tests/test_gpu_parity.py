@@ -251,3 +251,35 @@ def test_fused_path_other_depths_vs_oracle(layers, prune):
         check_grads(model, G, tol=2e-4)
     finally:
         Lb.set_default_options(no_prune_top=0)
+
+
+@pytest.mark.parametrize("V,B,L", [(5, 1, 50), (4, 2, 7), (3, 300, 12)])
+def test_degenerate_catalogue_and_batch_sizes_vs_oracle(V, B, L):
+    """One sequence, a catalogue of 2 - 4 real items (V not a multiple of 4, smaller than any tile), a batch that is not
+    a multiple of 32 / 64 / 256: loss and every gradient against the oracle (dropout on, shared Philox masks), pruned
+    and full top block."""
+    from oracle import bsarec_oracle as O
+    from bsarec_amd import _lib as Lb
+    for prune in (1, 0):
+        Lb.set_default_options(no_prune_top=1 - prune)
+        try:
+            cfg = O.Config(item_size=V, hidden_size=64, max_seq_length=L, num_hidden_layers=2, num_attention_heads=2,
+                           c=3, alpha=0.9, hidden_dropout_prob=0.3, attention_probs_dropout_prob=0.2)
+            params = O.init_params(cfg, seed=V + B)
+            rng = np.random.default_rng(V * 100 + B)
+            ids = np.zeros((B, L), dtype=np.int64)
+            for b in range(B):
+                n = int(rng.integers(0, L + 1))
+                if n:
+                    ids[b, L - n:] = rng.integers(1, V, size=n)
+            ans = rng.integers(1, V, size=B).astype(np.int64)
+            model = build_model(cfg, params)
+            model.train()
+            model.set_seed(31)
+            loss = model.calculate_loss(torch.from_numpy(ids).cuda(), torch.from_numpy(ans).cuda(), None, None, None)
+            loss.backward()
+            oloss, _, G, _ = O.loss_and_grads(params, cfg, ids, ans, O.DropoutSpec(True, 31, 1))
+            assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss), (loss.item(), oloss)
+            check_grads(model, G, tol=3e-4)
+        finally:
+            Lb.set_default_options(no_prune_top=0)
