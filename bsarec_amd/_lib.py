@@ -190,7 +190,8 @@ def source_sha16() -> str:
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(HERE, "csrc")
-    for f in sorted(os.listdir(src)) + [os.path.join(os.path.dirname(HERE), "include", "bsarec_hip.h")]:
+    for f in sorted(os.listdir(src)) + [os.path.join(os.path.dirname(HERE), "include", "bsarec_hip.h"),
+                                         os.path.join(HERE, "build.py")]:          # (build.py: the compiler flags)
         with open(f if os.path.isabs(f) else os.path.join(src, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
