@@ -113,8 +113,19 @@ class ShardedCatalogue:
         torch.cuda.synchronize(self.device)
         torch.distributed.barrier(group=self.group)
 
+    def check_exchange(self):
+        """The barrier kernel gives up after 5 s and sets a STICKY error word instead of hanging; a step that ran past a
+        timed-out barrier read incomplete peer memory.  Call once per epoch / before a checkpoint (``full_state_dict``
+        does): the flag is MAX-reduced so that every rank raises."""
+        bad = torch.tensor([1.0 if self.px.timed_out() else 0.0], device=self.device)
+        torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        if bad.item() != 0.0:
+            raise RuntimeError("catalogue-sharded step: a cross-GPU barrier timed out on some rank (sticky error word); "
+                               "shards and replicas can no longer be trusted")
+
     def full_state_dict(self):
         """The reference's state dict (full item table gathered from the owners; checkpoints of small catalogues, tests)."""
+        self.check_exchange()
         parts = [torch.empty_like(self.E) for _ in range(self.W)]
         torch.distributed.all_gather(parts, self.E.contiguous(), group=self.group)
         sd = {k: v.detach().clone() for k, v in self.encoder.state_dict().items()}

@@ -233,3 +233,40 @@ def test_dropout_step_counter_is_never_reused_across_the_epoch_tail():
         tr.train(ep)
     assert len(used) == 3 * 4
     assert all(b > a for a, b in zip(used, used[1:])), used
+
+
+def test_bench_command_of_the_driver_builds_no_graph_on_the_clock():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command, BENCH_r02.json): every graph of the run is
+    built by Feed.prepare() before t0 (timed_steps asserts it), 20 steps = a 16-step and a 4-step graph launch, and the
+    result equals 20 eager steps from the same state (same Philox stream, same batches)."""
+    import bench
+    from bsarec_amd import BSARecModel, data as D
+    from bsarec_amd.trainer import Trainer, graph_sizes
+    a = argparse.Namespace(item_size=301, hidden=64, seq_len=50, batch=32, layers=2, heads=2, dtype="f32")
+    margs = bench.model_args(a)
+    seqs = D.synth_ml1m_like(seed=3, n_users=200, n_items=300)
+    u, x, y = D.train_table(seqs, 50)
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = BSARecModel(margs).cuda()
+        model.set_seed(9)
+        model.train()
+        bt = D.DeviceBatches(u, x, y, 32, "cuda", shuffle=True, seed=4)
+        tr = Trainer(model, bt, None, None, margs, None, use_graph=graph)
+        fd = bench.Feed(tr, bt, "cuda")
+        dt, loss = bench.timed_steps(fd, 20, 5, torch.cuda.synchronize)
+        return tr, fd, float(loss.item()), model._arena.clone()
+    tr, fd, loss_g, arena_g = run(True)
+    assert tr.graphs_built() == len(graph_sizes(16))
+    ran = fd.pos // 32
+    tr2, fd2, loss_e, arena_e = run(False)
+    # the eager run took fewer untimed steps (no graphs to build): bring it to the same step count before comparing
+    assert fd2.pos // 32 == 25 and ran > 25
+    fd2.run(ran - 25)
+    torch.cuda.synchronize()
+    # (float atomics in the embedding scatter: arrival order differs run to run, Adam turns a sign flip of a ~0 gradient
+    #  into a +-lr step -- compare up to a small fraction of such elements, as the graph-vs-eager test does)
+    bad = (arena_g - tr2.model._arena).abs() > 5e-5
+    print("graph vs eager after", ran, "steps: fraction off", bad.float().mean().item())
+    assert bad.float().mean().item() <= 1e-2

@@ -86,3 +86,47 @@ def test_two_ranks_equal_each_other_and_the_global_batch(graph, exchange, tmp_pa
         got, want = r0[k], sd[k].detach().cpu().numpy()
         bad = np.abs(got - want) > 2e-5
         assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - want).max())
+
+
+def _prepare_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from bsarec_amd import BSARecModel, data as D
+    from bsarec_amd.trainer import Trainer, graph_sizes
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        u, x, a_ = _table()
+        u, x, a_ = (np.concatenate([t] * 16) for t in (u, x, a_))          # 128 steps per rank and epoch
+        torch.manual_seed(1)
+        model = BSARecModel(_ns()).cuda()
+        model.set_seed(5, rank)
+        dl = D.DeviceBatches(u, x, a_, 64, "cuda", shuffle=True, seed=11, rank=rank, world=world)
+        tr = Trainer(model, dl, None, None, _ns(), None, use_graph=True, process_group=dist.group.WORLD, exchange="p2p")
+        tr.steps_per_graph = 4
+        perm = dl.local_permutation()
+        cur = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ran = tr.prepare_indexed(dl, perm, cur, None)
+        n0 = tr.graphs_built()
+        # single-step graphs for both parities + one graph per (group size, parity)
+        assert n0 == 2 + 2 * (len(graph_sizes(4)) - 1), (n0, sorted(map(str, tr._graphs)))
+        for n in (7, 4, 1, 2, 9):                       # every mix of group sizes, starting at either parity
+            tr.indexed_steps(dl, perm, cur, None, n)
+            ran += n
+        torch.cuda.synchronize()
+        assert tr.graphs_built() == n0, "indexed_steps captured a graph after prepare_indexed"
+        assert int(cur.item()) == ran * 64
+        tr.check_exchange()
+        np.savez(os.path.join(out_dir, f"prep{rank}.npz"), arena=model._arena.cpu().numpy(), ran=ran)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prepare_indexed_builds_every_graph_up_front_p2p(tmp_path):
+    """Trainer.prepare_indexed under the peer-to-peer exchange (two step parities): afterwards indexed_steps() of any
+    length captures nothing, the device cursor advanced by exactly the steps run, and the replicas are bit-identical."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_prepare_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "prep0.npz"), np.load(tmp_path / "prep1.npz")
+    assert int(r0["ran"]) == int(r1["ran"])
+    np.testing.assert_array_equal(r0["arena"], r1["arena"])

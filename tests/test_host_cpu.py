@@ -237,3 +237,58 @@ int main(void) {
         assert r.returncode == 0, r.stdout + r.stderr
         ver, ws, bad = r.stdout.split()
         assert int(ver) >= 3 and int(ws) > 100_000_000 and int(bad) == 0
+
+
+def test_graph_schedule_only_uses_sizes_prepare_indexed_builds():
+    """bench.py / Trainer.train replay groups of steps as one hipGraph launch.  Every group size indexed_steps() can ask
+    for must be one of graph_sizes(k) -- the set Trainer.prepare_indexed captures BEFORE the timed region (round-2 VERDICT:
+    the driver's `--steps 20 --warmup 5` used to capture a 16-step graph on the clock)."""
+    from bsarec_amd.trainer import graph_schedule, graph_sizes
+    for k in (1, 2, 3, 5, 8, 12, 16, 32):
+        sizes = set(graph_sizes(k))
+        assert 1 in sizes and k in sizes and len(sizes) <= 7
+        for n in range(0, 4 * k + 40):
+            sched = graph_schedule(n, k)
+            assert sum(sched) == n and set(sched) <= sizes, (k, n, sched)
+    assert graph_schedule(20, 16) == [16, 4]            # the driver's command line
+
+
+def test_bench_timed_region_builds_no_graph():
+    """bench.timed_steps with a stand-in trainer: prepare() runs before the clock, and a graph built between t0 and t1 is
+    an assertion failure, not a slower number."""
+    import bench
+
+    class FakeTrainer:
+        steps_per_graph = 16
+
+        def __init__(self, lazy):
+            self.lazy, self.graphs, self.calls = lazy, set(), []
+
+        def graphs_built(self):
+            return len(self.graphs)
+
+        def prepare_indexed(self, bt, pbuf, cursor, loss_sum):
+            if not self.lazy:
+                from bsarec_amd.trainer import graph_sizes
+                self.graphs |= set(graph_sizes(self.steps_per_graph))
+            self.calls.append("prepare")
+            return 33
+
+        def indexed_steps(self, bt, pbuf, cursor, loss_sum, n):
+            from bsarec_amd.trainer import graph_schedule
+            self.graphs |= set(graph_schedule(n, self.steps_per_graph))
+            self.calls.append(n)
+            return torch.zeros(())
+
+    class Bt:
+        batch_size, epoch = 4, 0
+        answers = torch.zeros(4 * 4000, dtype=torch.int64)
+
+        def local_permutation(self):
+            return torch.arange(4 * 4000)
+
+    tr = FakeTrainer(lazy=False)
+    dt, _ = bench.timed_steps(bench.Feed(tr, Bt(), "cpu"), 20, 5, lambda: None)
+    assert tr.calls == ["prepare", 5, 20] and dt >= 0
+    with pytest.raises(AssertionError, match="captured inside the timed region"):
+        bench.timed_steps(bench.Feed(FakeTrainer(lazy=True), Bt(), "cpu"), 20, 5, lambda: None)
