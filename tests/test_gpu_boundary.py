@@ -221,7 +221,8 @@ def test_dropout_step_counter_is_never_reused_across_the_epoch_tail():
 
     def spy_idx(*x, **k):
         r = orig_idx(*x, **k)
-        used.append(int(model._state[1].item()) - 1)      # used the value before its closing increment
+        s = int(model._state[1].item())                    # a group of _last_multi steps replays as one graph launch:
+        used.extend(range(s - tr._last_multi, s))         # each used the value before its closing increment
         return r
 
     def spy_eager(*x, **k):
