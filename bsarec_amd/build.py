@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bsarec_hip.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("bsarec_hip.hip", "common.h", "gemm.h", "epilogues.h", "kernels.h", "fused_layer.h", "dw_direct.h", "fused_top.h", "comm.h", "catalogue_shard.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("bsarec_hip.hip", "common.h", "gemm.h", "epilogues.h", "kernels.h", "fused_layer.h", "dw_direct.h", "fused_top.h", "fused_chain.h", "comm.h", "catalogue_shard.h")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "bsarec_hip.h"))
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "bsarec_comm.h"))
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "bsarec_shard.h"))

@@ -6,6 +6,7 @@
 #include "fused_layer.h"
 #include "dw_direct.h"
 #include "fused_top.h"
+#include "fused_chain.h"
 #include "comm.h"
 #include "catalogue_shard.h"
 
@@ -559,9 +560,25 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
     F.drop_o = make_drop(p, c.p_hidden, 3 + 4 * l, tr); F.drop_ff = make_drop(p, c.p_hidden, 4 + 4 * l, tr);
     F.trash = p.trash;
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
-    const size_t smem = fused_fwd_smem_bytes();
     TopFwdP TF;
     if (top_tail) fill_top_fwd(p, l + 1, tr, TF);
+    if (!p.bf && !c.phase_kernels) {
+        // register-chain forward (fused_chain.h): one wave per 16-token tile, two workgroup barriers
+        const size_t csm = fused_chain_fwd_smem_bytes(top_tail);
+#define CHAIN_FWD_CASE(DHV) { \
+        static bool attr = false, attr_t = false; \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_chain_fwd_kernel<DHV, NoTail>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_chain_fwd_smem_bytes(false))); attr = true; } \
+        if (!attr_t) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_chain_fwd_kernel<DHV, TopFwdP>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_chain_fwd_smem_bytes(true))); attr_t = true; } \
+        ProfScope prof(BSAREC_K_FUSED_FWD, s); \
+        if (top_tail) LAUNCH((fused_chain_fwd_kernel<DHV, TopFwdP>), dim3(c.batch), dim3(512), csm, s, F, TF); \
+        else LAUNCH((fused_chain_fwd_kernel<DHV, NoTail>), dim3(c.batch), dim3(512), csm, s, F, NoTail()); }
+        if (p.dh == 16) CHAIN_FWD_CASE(16) else if (p.dh == 32) CHAIN_FWD_CASE(32) else CHAIN_FWD_CASE(64)
+#undef CHAIN_FWD_CASE
+        return (int)hipGetLastError();
+    }
+    const size_t smem = fused_fwd_smem_bytes();
 #define FUSED_FWD_CASE(DHV, BFV) { \
         static bool attr = false, attr_t = false; \
         if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV, NoTail>), \

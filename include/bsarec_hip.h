@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define BSAREC_MAX_LAYERS 16
-#define BSAREC_ABI_VERSION 5
+#define BSAREC_ABI_VERSION 6
 
 /* Hyper-parameters the reference model reads from `args`
  * (src/utils.py:83-96; src/model/bsarec.py:71-88; src/model/_modules.py:79-87). */
@@ -56,11 +56,13 @@ typedef struct {
     int no_fused;       /* 1: never take the fused per-sequence block kernels (hidden = 64, L <= 64, cutoff_bins <= 8) */
     int no_prune_top;   /* 1: bsarec_forward_last evaluates the full top block (no one-row evaluation) */
     int dw_tiled;       /* 1: LDS-tiled grouped weight-gradient kernel at the fused shape too (default: direct split-K) */
-    int splits;         /* split-K slab slices of the weight-gradient products (0: 40) */
+    int splits;         /* split-K slab slices of the weight-gradient products (0: 32 at the fused shape, 40 elsewhere) */
     int top_slabs;      /* slab slices of the one-row top block's weight-gradient products (0: 2) */
     int separate_embed; /* 1: the embedding front-end runs as its own kernel on the fused path too */
     int separate_top;   /* 1: the one-row top block of the loss path runs as its own kernels instead of as the tail /
                          * head of the launches of the block below it */
+    int phase_kernels;  /* 1: the round-2 LDS-phase block kernels (fused_layer.h) instead of the register-chain kernels
+                         * (fused_chain.h) at the fused shape in fp32; storage = 1 always takes the former */
 } bsarec_config_t;
 
 /* The 19 tensors of one BSARecBlock, in state_dict order (+ the sibling model's filter weight)
