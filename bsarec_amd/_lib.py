@@ -39,10 +39,10 @@ class Config(C.Structure):
                 # per-plan options, 0 = default (include/bsarec_hip.h)
                 ("hidden_act", C.c_int), ("storage", C.c_int), ("no_fused", C.c_int), ("no_prune_top", C.c_int),
                 ("dw_tiled", C.c_int), ("splits", C.c_int), ("top_slabs", C.c_int), ("separate_embed", C.c_int),
-                ("separate_top", C.c_int), ("phase_kernels", C.c_int)]
+                ("separate_top", C.c_int), ("chain_kernels", C.c_int)]
 
 
-OPTION_FIELDS = ("storage", "no_fused", "no_prune_top", "dw_tiled", "splits", "top_slabs", "separate_embed", "separate_top", "phase_kernels")
+OPTION_FIELDS = ("storage", "no_fused", "no_prune_top", "dw_tiled", "splits", "top_slabs", "separate_embed", "separate_top", "chain_kernels")
 HIDDEN_ACTS = {"gelu": 0, "relu": 1, "swish": 2, "tanh": 3, "sigmoid": 4}      # src/model/_modules.py:38-45
 
 # Plan options the HOST gives to plans it creates from now on.  The C ABI has no process-wide state: these are Python
@@ -64,7 +64,7 @@ def _env_defaults():
     if e.get("BSAREC_FUSED") == "0":
         d["no_fused"] = 1
     if e.get("BSAREC_BLOCK_KERNELS") == "phase":
-        d["phase_kernels"] = 1
+        d["chain_kernels"] = 1
     for env, key, hi in (("BSAREC_TOP_SLABS", "top_slabs", 16), ("BSAREC_SPLITS", "splits", 1024)):
         if e.get(env, "").isdigit() and 1 <= int(e[env]) <= hi:
             d[key] = int(e[env])

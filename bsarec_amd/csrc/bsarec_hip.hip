@@ -562,7 +562,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
     TopFwdP TF;
     if (top_tail) fill_top_fwd(p, l + 1, tr, TF);
-    if (!p.bf && !c.phase_kernels) {
+    if (!p.bf && c.chain_kernels) {
         // register-chain forward (fused_chain.h): one wave per 16-token tile, two workgroup barriers
         const size_t csm = fused_chain_fwd_smem_bytes(top_tail);
 #define CHAIN_FWD_CASE(DHV) { \

@@ -16,11 +16,15 @@
 // One wave owns a 16-token tile and carries it through the WHOLE attention branch + feed-forward in registers: bias,
 // softmax (lane = query, registers = keys), dropout, residual, LayerNorm (a token's 64 features = 16 registers x the 4
 // lanes n, n+16, n+32, n+48: two v_permlane swaps), erf-GELU, all on accumulators.  LDS carries only what tokens exchange:
-// the x tile, K, V^T (attention mixes tokens) and the FrequencyLayer output.  TWO workgroup barriers instead of ~25;
-// waves 0..3 = the four token tiles ("owners", one per SIMD), waves 4..7 = the FrequencyLayer of the same four tiles
-// (pruned DFT: every helper wave forms the 2 cb spectrum rows of ITS 4 features per lane over all tokens itself -- no
-// partial sums through LDS, no barrier) and exit.  Between the two barriers an owner never waits for another wave: its
-// vector work (GELU, Philox, LayerNorm) issues in the shadow of its own dependent MFMA chains.
+// the x tile, K, V^T (attention mixes tokens), the FrequencyLayer output and three small hand-overs inside a wave pair.
+// Measured on the way (tools/micro/, profiles/r03_micro_*): an fp32 MFMA occupies the SIMD's vector ALU -- while it
+// executes NO vector instruction of either resident wave issues (a bf16 MFMA does not do that) -- and one wave alone
+// issues a vector instruction only every ~4.4 cycles, two waves every ~2.  So for fp32 the SIMD's time is MFMA cycles +
+// VALU cycles, additive, and both waves of every SIMD must carry work.  Waves w and w + 4 (one SIMD) form a PAIR that owns
+// token tile w: they split the Q / K / V output slabs, the attention heads, the dense product (K-split), the
+// FrequencyLayer rows and the 16 inner slabs of the feed-forward, and meet three times through LDS (dense partial sums,
+// the mixed activation, the feed-forward partial sums).  All 8 waves stream the block's weights, coalesced, into a
+// two-slot LDS ring in MFMA-fragment order; one workgroup barrier per 16 KiB unit (14 units) + 3 hand-over barriers.
 // Same arithmetic (fp32 MFMA = fmaf chains), same Philox stream, same saved tensors as fused_layer_fwd_kernel; parity
 // against the oracle by the same tests (tests/test_gpu_parity.py runs both kernel sets).
 // src/model/bsarec.py:56-104, src/model/_modules.py:22-140.
@@ -122,44 +126,44 @@ __device__ __forceinline__ void chain_phase0(float* sX, int* sIds, float* sTab, 
 // ---- weight stream -----------------------------------------------------------------------------------------------
 // A fragment = 16 weight rows x 16 in-features = the A operands of 4 MFMAs for all 64 lanes = 1 KiB: lane (i, g) uses the
 // 16 bytes W[16 o + i][16 c + 4 g ..+3].  Read straight from global that is 16 cache lines per quarter-wave (the first
-// build of this kernel did: ~64 address-path cycles per wave instruction, x 4 owner waves -- the stamps showed every stage
-// 2.2-3x over its MFMA time).  So waves 4..7 stream the block's 196 KB of weights ONCE per workgroup with coalesced loads
-// (a quarter-wave = 256 contiguous bytes) into a two-slot LDS ring in fragment order, and the owners read their fragments
-// with one conflict-free ds_read_b128 each.  A unit = 8 fragments = 8 KiB = the weights of 32 MFMAs per owner:
-//   units 0..5   Wq, Wk, Wv as pairs of output slabs (32 rows x 64)         frag = 4 (slab in pair) + in-feature chunk
-//   units 6..7   Wo, the same way
-//   units 8 + s  feed-forward pipeline step s = 0..17: frags 0..3 = W1 output slab s (s < 16), frags 4..7 = W2 inner
-//                chunk s - 2 as 4 output slabs (s >= 2)
-// Piece (i, g) of a fragment sits at 16-byte position 4 i + (g ^ f(i >> 2)), f = {0, 3, 2, 1}: the owners' b128 reads
-// (lane groups {0-3, 12-15, 20-27}, ...) and the loaders' b128 writes (8 lanes = one weight row of two fragments) are
-// both at most 2-way on the LDS banks (reads: conflict-free).
-// Hand-shake: ONE workgroup barrier per unit.  Barrier E_k: unit k is complete in slot k & 1.  Loaders write unit k
-// between E_{k-1} and E_k; owners read unit k into registers between E_k and E_{k+1} and multiply with it after E_{k+1}
-// (second register set), so slot k & 1 is free again when the loaders pass E_{k+1}.
-constexpr int CHAIN_UNITS = 26;
+// build of this kernel did: ~64 address-path cycles per wave instruction; the stamps showed every stage 2-3x over its MFMA
+// time).  So the 8 waves stream the block's 196 KB of weights ONCE per workgroup with coalesced loads (a quarter-wave =
+// 256 contiguous bytes of a weight row) into a two-slot LDS ring in fragment order, and every wave reads its fragments
+// with one conflict-free ds_read_b128 each.  A unit = 16 fragments = 16 KiB = the weights of 32 MFMAs for each wave of a pair:
+//   units 0..3   Wq, Wk, Wv, Wo (whole matrices)                     frag = 4 (output slab) + in-feature chunk
+//   units 4 + s  feed-forward pipeline step s = 0..9:  frags 0..3 / 4..7 = W1 output slab s / 8 + s (s < 8),
+//                frags 8..11 / 12..15 = W2 inner chunk s - 2 / 8 + s - 2 as 4 output slabs (s >= 2)
+// Piece (i, g) of a fragment sits at 16-byte position 4 i + (g ^ f(i >> 2)), f = {0, 3, 2, 1}: the b128 reads (lane
+// groups {0-3, 12-15, 20-27}, ...) are conflict-free on the LDS banks, the b128 writes (8 lanes = one weight row of two
+// fragments) 2-way.
+// Hand-shake: barrier_k = "unit k is complete in slot k & 1, and every wave is done with unit k - 1".  After it a wave
+// reads its fragments of unit k into registers, writes its share of unit k + 1 into the other slot (global loads
+// requested three units earlier), requests unit k + 4, and multiplies.
+constexpr int CHAIN_UNITS = 14;
 __device__ __forceinline__ int frag_pos(int i, int g) { return 4 * i + (g ^ ((4 - (i >> 2)) & 3)); }
 
 struct ChainW { const float *wq, *wk, *wv, *wo, *w1, *w2; };
 
-// loader wave lw (0..3), lane l: its two 16-byte pieces of unit K -> source pointer (null: no piece) and LDS float offset in the slot
+// wave w (0..7), lane l: its two 16-byte pieces of unit K -> source pointer (null: no piece) and LDS float offset in the slot
 template <int K>
-__device__ __forceinline__ void unit_piece(const ChainW& W, int lw, int l, int k2, const float*& src, int& dstoff) {
-    const int p = (2 * lw + k2) * 64 + l;                            // piece index 0..511 of the unit
-    if constexpr (K < 8) {
-        const float* M = K < 2 ? W.wq : (K < 4 ? W.wk : (K < 6 ? W.wv : W.wo));
-        const int row = p >> 4, col4 = p & 15;                       // 32 rows x 16 pieces, row-major = 8 KiB contiguous
-        src = M + (long)(32 * (K & 1) + row) * 64 + 4 * col4;
+__device__ __forceinline__ void unit_piece(const ChainW& W, int w, int l, int k2, const float*& src, int& dstoff) {
+    const int p = (2 * w + k2) * 64 + l;                             // piece index 0..1023 of the unit
+    if constexpr (K < 4) {
+        const float* M = K == 0 ? W.wq : (K == 1 ? W.wk : (K == 2 ? W.wv : W.wo));
+        const int row = p >> 4, col4 = p & 15;                       // 64 rows x 16 pieces, row-major = 16 KiB contiguous
+        src = M + (long)row * 64 + 4 * col4;
         dstoff = ((row >> 4) * 4 + (col4 >> 2)) * 256 + 4 * frag_pos(row & 15, col4 & 3);
     } else {
-        constexpr int S = K - 8;
-        if (p < 256) {                                               // W1 output slab S: 16 rows x 64 in-features, contiguous
-            const int row = p >> 4, col4 = p & 15;
-            src = S < 16 ? W.w1 + (long)(16 * S + row) * 64 + 4 * col4 : nullptr;
-            dstoff = (col4 >> 2) * 256 + 4 * frag_pos(row, col4 & 3);
-        } else {                                                     // W2 inner chunk S - 2: 64 rows x 16 in-features (64 B per row)
-            const int q = p - 256, row = q >> 2, g = q & 3;
-            src = S >= 2 ? W.w2 + (long)row * 256 + 16 * (S - 2) + 4 * g : nullptr;
-            dstoff = (4 + (row >> 4)) * 256 + 4 * frag_pos(row & 15, g);
+        constexpr int S = K - 4;
+        const int q = p >> 8, pp = p & 255;                          // q is wave-uniform: waves 0,1 / 2,3 / 4,5 / 6,7
+        if (q < 2) {                                                 // W1 output slab S (q = 0) or 8 + S (q = 1): 16 rows x 64, contiguous
+            const int row = pp >> 4, col4 = pp & 15;
+            src = S < 8 ? W.w1 + (long)(16 * (8 * q + S) + row) * 64 + 4 * col4 : nullptr;
+            dstoff = (4 * q + (col4 >> 2)) * 256 + 4 * frag_pos(row, col4 & 3);
+        } else {                                                     // W2 inner chunk S - 2 (q = 2) or 8 + S - 2 (q = 3): 64 rows x 64 B
+            const int row = pp >> 2, g = pp & 3;
+            src = S >= 2 ? W.w2 + (long)row * 256 + 16 * (8 * (q - 2) + S - 2) + 4 * g : nullptr;
+            dstoff = (8 + 4 * (q - 2) + (row >> 4)) * 256 + 4 * frag_pos(row & 15, g);
         }
     }
 }
@@ -172,229 +176,243 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     constexpr unsigned KOFF = (unsigned)((sizeof(FusedFwdP) + 7) & ~(size_t)7);     // kernarg offset of T_unused
     constexpr int NC = DH / 16;                 // 16-feature slabs per head
     constexpr int NH = 64 / DH;
+    constexpr int NQ = NH == 1 ? 4 : 2;         // Q slabs a wave forms (one head: both waves of a pair need the whole query)
+    constexpr int NHW = NH == 1 ? 1 : NH / 2;   // heads per wave
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TS = 64 * FS;
-    float* sX = sm;                             // T0: x tile [token][feature]; TAIL: the block's output tile at the end
+    float* sX = sm;                             // T0: x tile [token][feature]; then the pair hand-overs; TAIL: the block's output tile
     float* sD = sm + TS;                        // T1: FrequencyLayer output (dsp); TAIL: the tail's row vectors
     float* sK = sm + 2 * TS;                    // T2: K [token][feature]
     float* sVt = sm + 3 * TS;                   // T3: V^T [feature][token]
-    float* sRing = sm + 4 * TS;                 // T4: weight ring, 2 slots x 2048 floats (TAIL: T4..T5 = the tail's DFT partials later)
-    constexpr int NT = TAIL ? 6 : 5;
-    static_assert(2 * 2048 <= TS, "ring must fit one tile");
-    float* sTab = sm + NT * TS;                 // FUSED_MAX_CB * 128
+    float* sRing = sm + 4 * TS;                 // T4..T5: weight ring, 2 slots x 4096 floats (TAIL: the tail's DFT partials later)
+    static_assert(2 * 4096 <= 2 * TS, "ring must fit two tiles");
+    float* sTab = sm + 6 * TS;                  // FUSED_MAX_CB * 128
     float* sSpec = sTab + FUSED_MAX_CB * 128;   // FUSED_MAX_CB * 128 (tail only)
     int* sIds = reinterpret_cast<int*>(sSpec + FUSED_MAX_CB * 128);
+    float* sVec = reinterpret_cast<float*>(sIds + 64);              // the block's 12 bias / gamma / beta / sqrt_beta vectors + b1: 1024 floats
+    enum { V_BQ = 0, V_BK = 64, V_BV = 128, V_BO = 192, V_B2 = 256, V_FG = 320, V_FB = 384, V_AG = 448, V_AB = 512, V_FFG = 576,
+           V_FFB = 640, V_BETA = 704, V_B1 = 768 };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
+    const int half = wave >> 2, T = wave & 3;   // pair T = waves T, T + 4; half 0 finishes the row passes
     const int L = KARG(FusedFwdP, L), Lp = KARG(FusedFwdP, Lp), cb = KARG(FusedFwdP, cb);
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
-
-    STAMP(0);
-    const DropSeed dseed = drop_seed(KARG(FusedFwdP, drop_f));
-
-    if (wave >= 4) {
-        // ================= loaders (waves 4..7): weight stream + FrequencyLayer of token tile T =================
-        const int lw = wave - 4, T = lw;
-        const ChainW W = {KARG(FusedFwdP, wq), KARG(FusedFwdP, wk), KARG(FusedFwdP, wv), KARG(FusedFwdP, wo), KARG(FusedFwdP, w1), KARG(FusedFwdP, w2)};
-        constexpr int D = 3;                                         // units in flight in registers
-        f32x4 st[D][2];
-        auto issue = [&](auto kc) {
-            constexpr int K = decltype(kc)::value;
-            if constexpr (K < CHAIN_UNITS) {
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const float* src; int off;
-                    unit_piece<K>(W, lw, lane, k2, src, off);
-                    st[K % D][k2] = src ? gld4(src) : f32x4{0, 0, 0, 0};
-                }
-            }
-        };
-        auto fill = [&](auto kc) {
-            constexpr int K = decltype(kc)::value;
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const float* src; int off;
-                unit_piece<K>(W, lw, lane, k2, src, off);
-                st4(sRing + (K & 1) * 2048 + off, st[K % D][k2]);
-            }
-        };
-        issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{}); issue(std::integral_constant<int, 2>{});
-        __builtin_amdgcn_sched_barrier(0);
-        chain_phase0(sX, sIds, sTab, dseed, L, cb, tok0, b);
-        lds_barrier();                                               // ---- B0: x tile, ids, twiddles
-        // FrequencyLayer (src/model/bsarec.py:90-104) in slices between the unit barriers: spectrum, then 4 rows per slice
-        const int f4 = 4 * n;                                        // this lane's 4 features; g = row quarter
-        const bool tile_on = 16 * T < L;
-        f32x4 re[FUSED_MAX_CB], im[FUSED_MAX_CB];
-        auto spectrum = [&]() {
-#pragma unroll
-            for (int k = 0; k < FUSED_MAX_CB; ++k) { re[k] = f32x4{0, 0, 0, 0}; im[k] = re[k]; }
-#pragma unroll 4
-            for (int i = 0; i < 16; ++i) {
-                const int t = 16 * g + i;
-                const f32x4 xv = ld4(sX + t * FS + f4);              // rows >= L are zero (and so are their twiddles)
-#pragma unroll
-                for (int k = 0; k < FUSED_MAX_CB; ++k)
-                    if (k < cb) {
-                        const float c = sTab[2 * (k * 64 + t)], sn = sTab[2 * (k * 64 + t) + 1];
-                        re[k] += xv * c; im[k] -= xv * sn;
-                    }
-            }
-#pragma unroll
-            for (int k = 0; k < FUSED_MAX_CB; ++k)
-                if (k < cb) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { re[k][j] = quad_rows_sum(re[k][j]); im[k][j] = quad_rows_sum(im[k][j]); }
-                }
-        };
-        auto dsp_rows = [&](int p) {
-            const float* const sqrt_beta = KARG(FusedFwdP, sqrt_beta);
-            f32x4 b2 = gld4(sqrt_beta + f4);
-            b2 = b2 * b2;
-            const f32x4 fg = gld4(KARG(FusedFwdP, f_g) + f4), fb = gld4(KARG(FusedFwdP, f_b) + f4);
-            const DropP drop_f = KARG(FusedFwdP, drop_f);
-            const float eps = KARG(FusedFwdP, eps);
-            float* const xhat_f = KARG(FusedFwdP, xhat_f);
-            float* const rstd_f = KARG(FusedFwdP, rstd_f);
-            float* const dspG = KARG(FusedFwdP, dsp);
-            const float invL = 1.0f / (float)L;
-            const int t = 16 * T + 4 * p + g;
-            const bool ok = t < L;
-            const long e = (tok0 + t) * 64 + f4;
-            f32x4 v = {0, 0, 0, 0};
-            if (ok) {
-                const f32x4 xv = ld4(sX + t * FS + f4);
-                f32x4 low = {0, 0, 0, 0};
-#pragma unroll
-                for (int k = 0; k < FUSED_MAX_CB; ++k)
-                    if (k < cb) {
-                        const float w = (k == 0 || (2 * k == L)) ? 1.0f : 2.0f;
-                        const float c = sTab[2 * (k * 64 + t)] * w, sn = sTab[2 * (k * 64 + t) + 1] * w;
-                        low += re[k] * c - im[k] * sn;
-                    }
-                low = low * invL;
-                v = (low + b2 * (xv - low)) * drop_mult4(drop_f, dseed, (uint64_t)e >> 2) + xv;
-            }
-            const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
-            f32x4 dl = {0, 0, 0, 0};
-            if (ok) dl = v - mean;
-            const float var = group_sum<16>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * (1.0f / 64.0f);
-            const float rs = 1.0f / sqrtf(var + eps);
-            f32x4 y = {0, 0, 0, 0};
-            if (ok) {
-                const f32x4 xh = dl * rs;
-                y = fg * xh + fb;
-                gst4(xhat_f + e, xh);
-                if (dspG) gst4(dspG + e, y);
-                if (n == 0) gst(rstd_f + (tok0 + t), rs);
-            }
-            st4(sD + t * FS + f4, y);
-        };
-        // unit loop: write unit K to its slot, request unit K + D, one slice of the FrequencyLayer, barrier E_K
-#define LOADER_STEP(K, EXTRA) { fill(std::integral_constant<int, K>{}); issue(std::integral_constant<int, K + D>{}); EXTRA; lds_barrier(); }
-        LOADER_STEP(0, )
-        LOADER_STEP(1, if (tile_on) spectrum())
-        LOADER_STEP(2, if (tile_on) dsp_rows(0))
-        LOADER_STEP(3, if (tile_on) dsp_rows(1))
-        LOADER_STEP(4, if (tile_on) dsp_rows(2))
-        LOADER_STEP(5, if (tile_on) dsp_rows(3))
-        LOADER_STEP(6, { long long* st_ = KARG(FusedFwdP, stamps); if (st_ && blockIdx.x == 0 && threadIdx.x == 256) st_[9] = clock64(); })
-        LOADER_STEP(7, )                                             // E_7 = the K / V^T / dsp exchange barrier of the owners
-        LOADER_STEP(8, ) LOADER_STEP(9, ) LOADER_STEP(10, ) LOADER_STEP(11, ) LOADER_STEP(12, ) LOADER_STEP(13, )
-        LOADER_STEP(14, ) LOADER_STEP(15, ) LOADER_STEP(16, ) LOADER_STEP(17, ) LOADER_STEP(18, ) LOADER_STEP(19, )
-        LOADER_STEP(20, ) LOADER_STEP(21, ) LOADER_STEP(22, ) LOADER_STEP(23, ) LOADER_STEP(24, ) LOADER_STEP(25, )
-#undef LOADER_STEP
-        return;
-    }
-
-    // ================= owners (waves 0..3): token tile T through attention branch + feed-forward, in registers =================
-    // Scheduling notes.  (1) hipcc's machine scheduler sinks loads down to their first use (fewer live registers, no
-    // prefetch left) -- __builtin_amdgcn_sched_barrier(0) behind each fragment read pins it.  (2) Stores of padded token rows
-    // go to a trash line instead of being predicated: a predicated store is a branch, and a branch ends the scheduling
-    // region (MFMA / VALU interleaving stops at it).
-    chain_phase0(sX, sIds, sTab, dseed, L, cb, tok0, b);
-    lds_barrier();                                                   // ---- B0: x tile, ids, twiddles
-    STAMP(1);
-    const int T = wave, t = 16 * T + n;
+    const int t = 16 * T + n;
     const bool tile_on = 16 * T < L, ok = t < L;
     const long erow = (tok0 + t) * 64 + 4 * g;                       // element offset of this lane's 4 features of slab 0
     float* const trash = KARG(FusedFwdP, trash) + 4 * lane;
+    // stores of padded token rows go to a trash line instead of being predicated: a predicated store is a branch, and a
+    // branch ends the scheduling region
     auto dst = [&](float* base, long off) { return ok ? base + off : trash; };
-    const float* const myfrag = sRing + 4 * frag_pos(n, g);          // this lane's piece inside fragment 0 of slot 0
-    f32x4 ws[2][8];                                                  // two register sets of 8 fragments
-    auto rd_unit = [&](int k, f32x4 (&wd)[8]) {
+
+    STAMP(0);
+    const DropSeed dseed = drop_seed(KARG(FusedFwdP, drop_f));
+    const ChainW W = {KARG(FusedFwdP, wq), KARG(FusedFwdP, wk), KARG(FusedFwdP, wv), KARG(FusedFwdP, wo), KARG(FusedFwdP, w1), KARG(FusedFwdP, w2)};
+    constexpr int D = 3;                                             // units in flight in registers
+    f32x4 st[D][2];
+    auto issue = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        if constexpr (K < CHAIN_UNITS) {
 #pragma unroll
-        for (int f = 0; f < 8; ++f) wd[f] = ld4(myfrag + (k & 1) * 2048 + f * 256);
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const float* src; int off;
+                unit_piece<K>(W, wave, lane, k2, src, off);
+                st[K % D][k2] = src ? gld4(src) : f32x4{0, 0, 0, 0};
+            }
+        }
     };
-    f32x4 x[4], q[4];
+    auto fill = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        if constexpr (K < CHAIN_UNITS) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { x[c] = f32x4{0, 0, 0, 0}; q[c] = x[c]; }
-    if (tile_on) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) x[c] = ld4(sX + t * FS + 16 * c + 4 * g);
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const float* src; int off;
+                unit_piece<K>(W, wave, lane, k2, src, off);
+                st4(sRing + (K & 1) * 4096 + off, st[K % D][k2]);
+            }
+        }
+    };
+    issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{}); issue(std::integral_constant<int, 2>{});
+    {   // the small per-feature vectors go through LDS once: read where they are needed, a global load would expose an L2 round
+        // trip on the single chain of a wave (the stamps of the first pair build: 2-3 k cycles per LayerNorm stage)
+        const float* v0 = wave == 0 ? KARG(FusedFwdP, bq) : wave == 1 ? KARG(FusedFwdP, bk) : wave == 2 ? KARG(FusedFwdP, bv) : wave == 3 ? KARG(FusedFwdP, bo) :
+                          wave == 4 ? KARG(FusedFwdP, b2) : wave == 5 ? KARG(FusedFwdP, f_g) : wave == 6 ? KARG(FusedFwdP, f_b) : KARG(FusedFwdP, a_g);
+        const float* v1 = wave == 0 ? KARG(FusedFwdP, a_b) : wave == 1 ? KARG(FusedFwdP, ff_g) : wave == 2 ? KARG(FusedFwdP, ff_b) : wave == 3 ? KARG(FusedFwdP, sqrt_beta) :
+                          KARG(FusedFwdP, b1) + 64 * (wave - 4);
+        sVec[64 * wave + lane] = gld(v0 + lane);
+        sVec[512 + 64 * wave + lane] = gld(v1 + lane);
     }
-    // ---- Q, K, V projections: unit u = output slabs 2 (u & 1), +1 of [Q | K | V]: two independent accumulator chains
+    __builtin_amdgcn_sched_barrier(0);
+    chain_phase0(sX, sIds, sTab, dseed, L, cb, tok0, b);
+    fill(std::integral_constant<int, 0>{});
+    issue(std::integral_constant<int, 3>{});
+    STAMP(1);
+
+    const float* const myfrag = sRing + 4 * frag_pos(n, g);          // this lane's piece inside fragment 0 of slot 0
+    f32x4 wf[8];
+    // after barrier_K: fragments f0 + {0..3} and f1 + {0..3} of unit K -> registers; this wave's share of unit K + 1 -> the
+    // other slot; unit K + 4 requested.  hipcc's scheduler sinks loads to their first use: sched_barrier pins them here.
+#define UNIT_BEGIN(K, f0, f1) { \
+        lds_barrier(); \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f) { wf[f] = ld4(myfrag + ((K) & 1) * 4096 + ((f0) + f) * 256); \
+                                                          wf[4 + f] = ld4(myfrag + ((K) & 1) * 4096 + ((f1) + f) * 256); } \
+        fill(std::integral_constant<int, (K) + 1>{}); issue(std::integral_constant<int, (K) + 4>{}); \
+        __builtin_amdgcn_sched_barrier(0); }
+
+    // ---- FrequencyLayer (src/model/bsarec.py:90-104) in three slices beside the Q / K / V projections: both waves of a pair
+    //      form the 2 cb spectrum rows of their 4 features per lane over ALL tokens (no partial sums through LDS, no
+    //      barrier), wave `half` then finishes rows 16 T + 4 (2 half + {0, 1}) + g of the tile
+    const int f4 = 4 * n;
+    f32x4 re[FUSED_MAX_CB], im[FUSED_MAX_CB];
+    auto spectrum = [&]() {
+#pragma unroll
+        for (int k = 0; k < FUSED_MAX_CB; ++k) { re[k] = f32x4{0, 0, 0, 0}; im[k] = re[k]; }
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int tt = 16 * g + i;
+            const f32x4 xv = ld4(sX + tt * FS + f4);                 // rows >= L are zero (and so are their twiddles)
+#pragma unroll
+            for (int k = 0; k < FUSED_MAX_CB; ++k)
+                if (k < cb) {
+                    const float c = sTab[2 * (k * 64 + tt)], sn = sTab[2 * (k * 64 + tt) + 1];
+                    re[k] += xv * c; im[k] -= xv * sn;
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < FUSED_MAX_CB; ++k)
+            if (k < cb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { re[k][j] = quad_rows_sum(re[k][j]); im[k][j] = quad_rows_sum(im[k][j]); }
+            }
+    };
+    auto dsp_rows = [&](int p) {
+        f32x4 b2 = ld4(sVec + V_BETA + f4);
+        b2 = b2 * b2;
+        const f32x4 fg = ld4(sVec + V_FG + f4), fb = ld4(sVec + V_FB + f4);
+        const DropP drop_f = KARG(FusedFwdP, drop_f);
+        const float eps = KARG(FusedFwdP, eps);
+        float* const xhat_f = KARG(FusedFwdP, xhat_f);
+        float* const rstd_f = KARG(FusedFwdP, rstd_f);
+        float* const dspG = KARG(FusedFwdP, dsp);
+        const float invL = 1.0f / (float)L;
+        const int tt = 16 * T + 4 * p + g;
+        const bool rok = tt < L;
+        const long e = (tok0 + tt) * 64 + f4;
+        f32x4 v = {0, 0, 0, 0};
+        if (rok) {
+            const f32x4 xv = ld4(sX + tt * FS + f4);
+            f32x4 low = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < FUSED_MAX_CB; ++k)
+                if (k < cb) {
+                    const float w = (k == 0 || (2 * k == L)) ? 1.0f : 2.0f;
+                    const float c = sTab[2 * (k * 64 + tt)] * w, sn = sTab[2 * (k * 64 + tt) + 1] * w;
+                    low += re[k] * c - im[k] * sn;
+                }
+            low = low * invL;
+            v = (low + b2 * (xv - low)) * drop_mult4(drop_f, dseed, (uint64_t)e >> 2) + xv;
+        }
+        const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
+        f32x4 dl = {0, 0, 0, 0};
+        if (rok) dl = v - mean;
+        const float var = group_sum<16>(dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w) * (1.0f / 64.0f);
+        const float rs = 1.0f / sqrtf(var + eps);
+        f32x4 y = {0, 0, 0, 0};
+        if (rok) {
+            const f32x4 xh = dl * rs;
+            y = fg * xh + fb;
+            gst4(xhat_f + e, xh);
+            if (dspG) gst4(dspG + e, y);
+            if (n == 0) gst(rstd_f + (tok0 + tt), rs);
+        }
+        st4(sD + tt * FS + f4, y);
+    };
+
+    // ---- Q, K, V projections: this wave's output slabs 2 half, 2 half + 1 (one attention head: also Q's other two)
+    f32x4 x[4], q[NQ];
+    const int o0 = 2 * half;
     {
-        const float* const bq = KARG(FusedFwdP, bq);
-        const float* const bk = KARG(FusedFwdP, bk);
-        const float* const bv = KARG(FusedFwdP, bv);
         float* const qG = KARG(FusedFwdP, q);
         float* const kG = KARG(FusedFwdP, k);
         float* const vG = KARG(FusedFwdP, v);
-        lds_barrier();                                               // ---- E_0
-        rd_unit(0, ws[0]);
+        UNIT_BEGIN(0, 8 * half, 8 * half + 4)                        // ---- barrier_0 (also: x tile, ids, twiddles, vectors, ring slot 0)
+        f32x4 bia[3][2];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            lds_barrier();                                           // ---- E_{u+1}
-            rd_unit(u + 1, ws[(u + 1) & 1]);
-            const float* B = u < 2 ? bq : (u < 4 ? bk : bv);
-            const int o0 = 2 * (u & 1);
-            f32x4 a0 = gld4(B + 16 * o0 + 4 * g), a1 = gld4(B + 16 * (o0 + 1) + 4 * g);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 2; ++j) {
+            bia[0][j] = ld4(sVec + V_BQ + 16 * (o0 + j) + 4 * g); bia[1][j] = ld4(sVec + V_BK + 16 * (o0 + j) + 4 * g); bia[2][j] = ld4(sVec + V_BV + 16 * (o0 + j) + 4 * g);
+        }
+        f32x4 bq2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        if (NH == 1) { bq2[0] = ld4(sVec + V_BQ + 16 * (2 - o0) + 4 * g); bq2[1] = ld4(sVec + V_BQ + 16 * (3 - o0) + 4 * g); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = tile_on ? ld4(sX + t * FS + 16 * c + 4 * g) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            f32x4 a0 = bia[u][0], a1 = bia[u][1];
             if (tile_on) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        a0 = mfma16(ws[u & 1][c][r], x[c][r], a0);
-                        a1 = mfma16(ws[u & 1][4 + c][r], x[c][r], a1);
+                        a0 = mfma16(wf[c][r], x[c][r], a0);
+                        a1 = mfma16(wf[4 + c][r], x[c][r], a1);
                     }
-                float* const G = u < 2 ? qG : (u < 4 ? kG : vG);
+                float* const G = u == 0 ? qG : (u == 1 ? kG : vG);
                 gst4(dst(G, erow + 16 * o0), a0); gst4(dst(G, erow + 16 * (o0 + 1)), a1);
-            } else { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }          // no token of this tile exists: K rows / V^T columns must still be
-            if (u < 2) {                                             // finite (the other owners' MFMAs read them; their P is exactly 0)
-                q[o0] = a0; q[o0 + 1] = a1;
-            } else if (u < 4) {
+            } else { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }          // no token of this tile exists: its K rows / V^T columns must still be
+            if (u == 0) {                                            // finite (the other pairs' MFMAs read them; their P is exactly 0)
+                q[NQ == 4 ? o0 : 0] = a0; q[NQ == 4 ? o0 + 1 : 1] = a1;
+                if (NH == 1 && tile_on) {                            // one head: the pair's other two Q slabs too (the whole query is this wave's B operand)
+                    f32x4 wq2[8];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) wq2[f] = ld4(myfrag + (8 * (1 - half) + f) * 256);
+                    f32x4 c0 = bq2[0], c1 = bq2[1];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { c0 = mfma16(wq2[c][r], x[c][r], c0); c1 = mfma16(wq2[4 + c][r], x[c][r], c1); }
+                    q[NQ == 4 ? 2 - o0 : 0] = c0; q[NQ == 4 ? 3 - o0 : 1] = c1;
+                }
+                if (tile_on) spectrum();
+            } else if (u == 1) {
                 st4(sK + t * FS + 16 * o0 + 4 * g, a0); st4(sK + t * FS + 16 * (o0 + 1) + 4 * g, a1);
+                if (tile_on) dsp_rows(2 * half);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     sVt[(16 * o0 + 4 * g + r) * FS + t] = a0[r];
                     sVt[(16 * (o0 + 1) + 4 * g + r) * FS + t] = a1[r];
                 }
+                if (tile_on) dsp_rows(2 * half + 1);
             }
+            if (u == 0) UNIT_BEGIN(1, 8 * half, 8 * half + 4)
+            if (u == 1) UNIT_BEGIN(2, 8 * half, 8 * half + 4)
         }
     }
     STAMP(2);
-    lds_barrier();                                                   // ---- E_7: Wo's second half; K, V^T of every tile and dsp are in LDS
-    rd_unit(7, ws[1]);                                               // (ws[0] holds unit 6 = Wo output slabs 0, 1)
+    // ---- unit 3 = Wo; barrier_3 also publishes K, V^T of every tile and dsp.  This wave's dense fragments: output slab o,
+    //      context chunks 2 half + {0, 1} -> wf[2 o + cc]
+    lds_barrier();
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { wf[2 * o] = ld4(myfrag + 4096 + (4 * o + 2 * half) * 256); wf[2 * o + 1] = ld4(myfrag + 4096 + (4 * o + 2 * half + 1) * 256); }
+    fill(std::integral_constant<int, 4>{}); issue(std::integral_constant<int, 7>{});
     __builtin_amdgcn_sched_barrier(0);
     STAMP(3);
-    f32x4 y[4], hm[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { y[c] = f32x4{0, 0, 0, 0}; hm[c] = y[c]; }
     const float eps = KARG(FusedFwdP, eps);
+    f32x4 a[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) a[o] = f32x4{0, 0, 0, 0};
     if (tile_on) {
-        // ---- attention, transposed: lane = query, registers = keys            src/model/_modules.py:118-135
+        // ---- attention of this wave's heads, transposed: lane = query, registers = keys      src/model/_modules.py:118-135
         const DropP drop_p = KARG(FusedFwdP, drop_p);
         float* const probsG = KARG(FusedFwdP, probs);
         float* const ctxG = KARG(FusedFwdP, ctx);
         const float inv_sqrt = 1.0f / sqrtf((float)DH);
-        f32x4 ctx[4];
+        f32x4 ctx[2];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
+        for (int hh = 0; hh < NHW; ++hh) {
+            const int h = NH == 1 ? 0 : half * NHW + hh;
             f32x4 s[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4{0, 0, 0, 0};
@@ -403,10 +421,11 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
                 f32x4 kf[4];
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) kf[kt] = ld4(sK + (16 * kt + n) * FS + h * DH + 16 * cc + 4 * g);
+                const f32x4 qs = q[NH == 1 ? cc : hh * NC + cc];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int kt = 0; kt < 4; ++kt) s[kt] = mfma16(kf[kt][r], q[h * NC + cc][r], s[kt]);
+                    for (int kt = 0; kt < 4; ++kt) s[kt] = mfma16(kf[kt][r], qs[r], s[kt]);
             }
             // scale, additive mask (-10000, fp32), softmax over keys = registers x the four lanes of this query
             float mx = -INFINITY;
@@ -416,7 +435,7 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
                 const int4 i4 = *reinterpret_cast<const int4*>(sIds + key0);
                 const int idk[4] = {i4.x, i4.y, i4.z, i4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {                        // (selects, not branches: a branch would end the scheduling region)
+                for (int r = 0; r < 4; ++r) {                        // (selects, not branches)
                     const int key = key0 + r;
                     const float add = (key <= t && idk[r] > 0) ? 0.0f : -10000.0f;
                     float sv = __fadd_rn(__fmul_rn(s[kt][r], inv_sqrt), add);      // scaled, THEN masked, two roundings as the reference's two ops
@@ -441,95 +460,120 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
             for (int kt = 0; kt < 4; ++kt) {
                 const int key0 = 16 * kt + 4 * g;
                 const f32x4 p = s[kt] * inv;
-                const bool pok = ok && key0 < Lp;                    // (elsewhere p is 0 or the row is not stored: any mask will do)
+                const bool pok = ok && key0 < Lp && (NH > 1 || half == 0);       // (one head: both waves hold the same row, one stores it)
                 const long e = (((long)b * NH + h) * L + (ok ? t : 0)) * Lp + (key0 < Lp ? key0 : 0);
                 gst4(pok ? probsG + e : trash, p);
                 s[kt] = p * drop_mult4(drop_p, dseed, (uint64_t)e >> 2);
             }
-            // ctx^T = V^T . Drop(P)^T  (the probability accumulators are the B operand as they stand)
+            // ctx^T = V^T . Drop(P)^T  (the probability accumulators are the B operand as they stand): this wave's context
+            // slabs = features 32 half .. 32 half + 31
+            constexpr int NF = NH == 1 ? 2 : NC;                     // context slabs produced per head pass
 #pragma unroll
-            for (int fc = 0; fc < NC; ++fc) ctx[h * NC + fc] = f32x4{0, 0, 0, 0};
+            for (int fc = 0; fc < NF; ++fc) ctx[NH == 1 ? fc : hh * NC + fc] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {                         // (unpopulated key tiles: K rows / V^T columns are zero, P is zero)
-                f32x4 vf[NC];
+                f32x4 vf[NF];
 #pragma unroll
-                for (int fc = 0; fc < NC; ++fc) vf[fc] = ld4(sVt + (h * DH + 16 * fc + n) * FS + 16 * kt + 4 * g);
+                for (int fc = 0; fc < NF; ++fc) vf[fc] = ld4(sVt + ((NH == 1 ? 32 * half : h * DH) + 16 * fc + n) * FS + 16 * kt + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int fc = 0; fc < NC; ++fc) ctx[h * NC + fc] = mfma16(vf[fc][r], s[kt][r], ctx[h * NC + fc]);
+                    for (int fc = 0; fc < NF; ++fc) ctx[NH == 1 ? fc : hh * NC + fc] = mfma16(vf[fc][r], s[kt][r], ctx[NH == 1 ? fc : hh * NC + fc]);
             }
-#pragma unroll
-            for (int fc = 0; fc < NC; ++fc) gst4(dst(ctxG, erow + 16 * (h * NC + fc)), ctx[h * NC + fc]);
         }
+        gst4(dst(ctxG, erow + 16 * o0), ctx[0]); gst4(dst(ctxG, erow + 16 * (o0 + 1)), ctx[1]);
         STAMP(4);
-        // ---- dense (units 6, 7 in the two register sets) + dropout + residual + LayerNorm + alpha mix
-        f32x4 a[4];
+        // ---- dense, K split inside the pair: this wave's two context slabs against all four output slabs
 #pragma unroll
-        for (int o = 0; o < 4; ++o) a[o] = gld4(KARG(FusedFwdP, bo) + 16 * o + 4 * g);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int o = 0; o < 4; ++o) a[o] = mfma16(ws[o >> 1][4 * (o & 1) + c][r], ctx[c][r], a[o]);
-        const DropP drop_o = KARG(FusedFwdP, drop_o);
-        {
-            f32x4 v[4], xh[4];
+                for (int o = 0; o < 4; ++o) a[o] = mfma16(wf[2 * o + cc][r], ctx[cc][r], a[o]);
+        if (half == 1) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) v[o] = a[o] * drop_mult4(drop_o, dseed, (uint64_t)(erow + 16 * o) >> 2) + x[o];
-            float rs;
-            ln_slabs(v, eps, xh, rs);
-            const float alpha = KARG(FusedFwdP, alpha), oma = KARG(FusedFwdP, oma);
-            float* const xhat_a = KARG(FusedFwdP, xhat_a);
-            float* const hmixG = KARG(FusedFwdP, hmix);
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const f32x4 ga = gld4(KARG(FusedFwdP, a_g) + 16 * o + 4 * g), ba = gld4(KARG(FusedFwdP, a_b) + 16 * o + 4 * g);
-                hm[o] = alpha * ld4(sD + t * FS + 16 * o + 4 * g) + oma * (ga * xh[o] + ba);
-                gst4(dst(xhat_a, erow + 16 * o), xh[o]); gst4(dst(hmixG, erow + 16 * o), hm[o]);
-            }
-            gst((ok && g == 0) ? KARG(FusedFwdP, rstd_a) + tok0 + t : trash, rs);
+            for (int o = 0; o < 4; ++o) st4(sX + t * FS + 16 * o + 4 * g, a[o]);       // (the x tile is dead: every wave holds its slabs)
         }
     }
+    lds_barrier();                                                   // ---- hand-over 1: the upper wave's dense partial sums
+    f32x4 hm[4], y[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { y[c] = f32x4{0, 0, 0, 0}; hm[c] = y[c]; }
+    if (tile_on && half == 0) {
+        // ---- + bias, dropout, residual, LayerNorm, alpha mix -> hmix (to the pair's other wave through LDS)
+        const DropP drop_o = KARG(FusedFwdP, drop_o);
+        f32x4 v[4], xh[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const f32x4 part = ld4(sX + t * FS + 16 * o + 4 * g) + ld4(sVec + V_BO + 16 * o + 4 * g);
+            v[o] = (a[o] + part) * drop_mult4(drop_o, dseed, (uint64_t)(erow + 16 * o) >> 2) + x[o];
+        }
+        float rs;
+        ln_slabs(v, eps, xh, rs);
+        const float alpha = KARG(FusedFwdP, alpha), oma = KARG(FusedFwdP, oma);
+        float* const xhat_a = KARG(FusedFwdP, xhat_a);
+        float* const hmixG = KARG(FusedFwdP, hmix);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const f32x4 ga = ld4(sVec + V_AG + 16 * o + 4 * g), ba = ld4(sVec + V_AB + 16 * o + 4 * g);
+            hm[o] = alpha * ld4(sD + t * FS + 16 * o + 4 * g) + oma * (ga * xh[o] + ba);
+            gst4(dst(xhat_a, erow + 16 * o), xh[o]); gst4(dst(hmixG, erow + 16 * o), hm[o]);
+            st4(sX + t * FS + 16 * o + 4 * g, hm[o]);
+        }
+        gst((ok && g == 0) ? KARG(FusedFwdP, rstd_a) + tok0 + t : trash, rs);
+    }
     STAMP(5);
-    // ---- feed-forward as a 3-stage pipeline over the 16 inner slabs, one weight unit per step s = 0..17:
-    //        MFMA   dense_1 slab s  (16, one chain; s < 16)              u_s = b1 + W1[slab s] . hmix^T
-    //        MFMA   dense_2 inner chunk s - 2  (16, four chains; s >= 2)  y  += W2[:, chunk s-2] . gelu(u_{s-2})
-    //        VALU   erf-GELU + GELU' on the accumulator of slab s - 1, both stored for the backward  (1 <= s <= 16)
-    //      so the ~200 vector instructions of a slab issue in the shadow of 32 MFMAs that do not wait for them.
+    // ---- feed-forward: this wave's 8 inner slabs j = 8 half + s as a 3-stage pipeline, one weight unit per step s = 0..9:
+    //        MFMA   dense_1 slab 8 half + s  (16, one chain; s < 8)          u_s = b1 + W1[slab] . hmix^T
+    //        MFMA   dense_2 inner chunk 8 half + s - 2  (16, four chains)     y  += W2[:, chunk] . gelu(u_{s-2})
+    //        VALU   erf-GELU + GELU' on the accumulator of step s - 1, both stored for the backward  (1 <= s <= 8)
     {
         float* const uG = KARG(FusedFwdP, u);
         float* const gpG = KARG(FusedFwdP, gp);
-        const float* const b1 = KARG(FusedFwdP, b1);
-        float* const udst = dst(uG, (tok0 + t) * 256 + 4 * g);
-        float* const gdst = dst(gpG, (tok0 + t) * 256 + 4 * g);
+        float* const udst = dst(uG, (tok0 + t) * 256 + 128 * half + 4 * g);
+        float* const gdst = dst(gpG, (tok0 + t) * 256 + 128 * half + 4 * g);
         const long ustep = ok ? 16 : 0;
+        if (half == 0) {
 #pragma unroll
-        for (int o = 0; o < 4; ++o) y[o] = gld4(KARG(FusedFwdP, b2) + 16 * o + 4 * g);
-        lds_barrier();                                               // ---- E_8
-        rd_unit(8, ws[0]);
+            for (int o = 0; o < 4; ++o) y[o] = ld4(sVec + V_B2 + 16 * o + 4 * g);
+        }
         f32x4 ucur = {0, 0, 0, 0}, glprev = {0, 0, 0, 0};
-        f32x4 bnext = gld4(b1 + 4 * g);
+        f32x4 bnext = ld4(sVec + V_B1 + 128 * half + 4 * g);
 #pragma unroll
-        for (int s = 0; s < 18; ++s) {
-            if (s + 1 < 18) { lds_barrier(); rd_unit(8 + s + 1, ws[(s + 1) & 1]); }      // ---- E_{9+s}
+        for (int s = 0; s < 10; ++s) {
+            // barrier_{4+s}; at s = 0 it is also hand-over 2: hmix of the tile is in LDS
+            lds_barrier();
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { wf[f] = ld4(myfrag + (s & 1) * 4096 + (4 * half + f) * 256); wf[4 + f] = ld4(myfrag + (s & 1) * 4096 + (8 + 4 * half + f) * 256); }
+            if (s == 0) { fill(std::integral_constant<int, 5>{}); issue(std::integral_constant<int, 8>{}); }
+            if (s == 1) { fill(std::integral_constant<int, 6>{}); issue(std::integral_constant<int, 9>{}); }
+            if (s == 2) { fill(std::integral_constant<int, 7>{}); issue(std::integral_constant<int, 10>{}); }
+            if (s == 3) { fill(std::integral_constant<int, 8>{}); issue(std::integral_constant<int, 11>{}); }
+            if (s == 4) { fill(std::integral_constant<int, 9>{}); issue(std::integral_constant<int, 12>{}); }
+            if (s == 5) { fill(std::integral_constant<int, 10>{}); issue(std::integral_constant<int, 13>{}); }
+            if (s == 6) fill(std::integral_constant<int, 11>{});
+            if (s == 7) fill(std::integral_constant<int, 12>{});
+            if (s == 8) fill(std::integral_constant<int, 13>{});
+            if (s == 0 && half == 1 && tile_on) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) hm[o] = ld4(sX + t * FS + 16 * o + 4 * g);
+            }
             f32x4 unext = bnext;
-            if (s + 1 < 16) bnext = gld4(b1 + 16 * (s + 1) + 4 * g);
+            if (s + 1 < 8) bnext = ld4(sVec + V_B1 + 128 * half + 16 * (s + 1) + 4 * g);
             __builtin_amdgcn_sched_barrier(0);
             if (tile_on) {
                 float gq[4] = {0.f, 0.f, 0.f, 0.f}, gpq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (s >= 1 && s <= 16) gelu_both(ucur[r], gq[r], gpq[r]);
+                    if (s >= 1 && s <= 8) gelu_both(ucur[r], gq[r], gpq[r]);
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
-                        if (s >= 2) y[o] = mfma16(ws[s & 1][4 + o][r], glprev[r], y[o]);
-                        if (s < 16) unext = mfma16(ws[s & 1][o][r], hm[o][r], unext);      // (chunk c = o of slab s)
+                        if (s >= 2) y[o] = mfma16(wf[4 + o][r], glprev[r], y[o]);
+                        if (s < 8) unext = mfma16(wf[o][r], hm[o][r], unext);          // (chunk c = o of the slab)
                     }
                 }
                 const f32x4 gl = {gq[0], gq[1], gq[2], gq[3]}, gd = {gpq[0], gpq[1], gpq[2], gpq[3]};
-                if (s >= 1 && s <= 16) { gst4(udst + ustep * (s - 1), gl); gst4(gdst + ustep * (s - 1), gd); }
+                if (s >= 1 && s <= 8) { gst4(udst + ustep * (s - 1), gl); gst4(gdst + ustep * (s - 1), gd); }
                 glprev = gl;
                 ucur = unext;
             }
@@ -537,19 +581,30 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         }
     }
     STAMP(6);
+    if (half == 1) {
+        if (tile_on) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) st4(sX + t * FS + 16 * o + 4 * g, y[o]);
+        }
+        { long long* st_ = KARG(FusedFwdP, stamps); if (st_ && blockIdx.x == 0 && threadIdx.x == 256) st_[9] = clock64(); }
+        lds_barrier();                                               // ---- hand-over 3 (upper wave's side): its feed-forward partial sums
+        return;
+    }
+    lds_barrier();                                                   // ---- hand-over 3
     if (tile_on) {
         // ---- dropout + residual + LayerNorm -> block output
         const DropP drop_ff = KARG(FusedFwdP, drop_ff);
         f32x4 v[4], xh[4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) v[o] = y[o] * drop_mult4(drop_ff, dseed, (uint64_t)(erow + 16 * o) >> 2) + hm[o];
+        for (int o = 0; o < 4; ++o)
+            v[o] = (y[o] + ld4(sX + t * FS + 16 * o + 4 * g)) * drop_mult4(drop_ff, dseed, (uint64_t)(erow + 16 * o) >> 2) + hm[o];
         float rs;
         ln_slabs(v, eps, xh, rs);
         float* const xhat_ff = KARG(FusedFwdP, xhat_ff);
         float* const Xout = KARG(FusedFwdP, Xout);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const f32x4 gf = gld4(KARG(FusedFwdP, ff_g) + 16 * o + 4 * g), bf = gld4(KARG(FusedFwdP, ff_b) + 16 * o + 4 * g);
+            const f32x4 gf = ld4(sVec + V_FFG + 16 * o + 4 * g), bf = ld4(sVec + V_FFB + 16 * o + 4 * g);
             y[o] = ok ? gf * xh[o] + bf : f32x4{0, 0, 0, 0};
             gst4(dst(xhat_ff, erow + 16 * o), xh[o]); gst4(dst(Xout, erow + 16 * o), y[o]);
         }
@@ -565,13 +620,15 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         top_fwd_prefetch<false, KOFF>(TR);
 #pragma unroll
         for (int o = 0; o < 4; ++o) st4(sX + t * FS + 16 * o + 4 * g, y[o]);
-        lds_barrier();                                               // ---- (owners only: waves 4..7 have exited)
+        lds_barrier();                                               // ---- (waves 0..3 only: waves 4..7 have exited)
         STAMP(8);
-        top_fwd_rest<DH, false, KOFF>(TR, dseed, sX, sK, sVt, sm + 4 * TS, sTab, sSpec, sD, sIds);
+        top_fwd_rest<DH, false, KOFF>(TR, dseed, sX, sK, sVt, sRing, sTab, sSpec, sD, sIds);
     }
+#undef UNIT_BEGIN
 }
 #undef PTYPE
 
 static inline size_t fused_chain_fwd_smem_bytes(bool tail) {
-    return (size_t)((tail ? 6 : 5) * 64 * FS + 2 * FUSED_MAX_CB * 128 + 64) * 4;
+    (void)tail;
+    return (size_t)(6 * 64 * FS + 2 * FUSED_MAX_CB * 128 + 64 + 1024) * 4;
 }

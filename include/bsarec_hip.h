@@ -61,8 +61,9 @@ typedef struct {
     int separate_embed; /* 1: the embedding front-end runs as its own kernel on the fused path too */
     int separate_top;   /* 1: the one-row top block of the loss path runs as its own kernels instead of as the tail /
                          * head of the launches of the block below it */
-    int phase_kernels;  /* 1: the round-2 LDS-phase block kernels (fused_layer.h) instead of the register-chain kernels
-                         * (fused_chain.h) at the fused shape in fp32; storage = 1 always takes the former */
+    int chain_kernels;  /* 1: the register-chain forward block kernel (fused_chain.h: lane = token, accumulators chained as MFMA
+                         * operands, LDS weight ring) instead of the LDS-phase kernel (fused_layer.h) at the fused shape in
+                         * fp32; measured equal in speed on MI355X, kept selectable */
 } bsarec_config_t;
 
 /* The 19 tensors of one BSARecBlock, in state_dict order (+ the sibling model's filter weight)
