@@ -363,34 +363,46 @@ def main():
     def timed(fd, steps, warmup):
         return timed_steps(fd, steps, warmup, barrier)
 
-    def replicas_agree(mdl, tr):
+    def replicas_state(mdl, tr):
         """Only gradients are exchanged: after any number of steps the parameter checksum must be the same on every rank
-        (and no peer-to-peer wait may have given up)."""
+        (and no peer-to-peer wait may have given up).  -> (agree, lowest checksum, highest checksum, a wait timed out)"""
         cs = mdl._arena.double().sum().view(1)
         lo, hi = cs.clone(), cs.clone()
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=pg)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=pg)
         bad = torch.tensor([1.0 if (tr.exchange == "p2p" and tr._px.timed_out()) else 0.0], device=dev)
         torch.distributed.all_reduce(bad, op=torch.distributed.ReduceOp.MAX, group=pg)
-        return bool(lo.item() == hi.item()) and bad.item() == 0.0
+        return bool(lo.item() == hi.item()) and bad.item() == 0.0, float(lo.item()), float(hi.item()), bool(bad.item() != 0.0)
+
+    def replicas_agree(mdl, tr):
+        return replicas_state(mdl, tr)[0]
 
     model.train()
     dt, loss = timed(feed, a.steps, a.warmup)
     p2p_rerun = None
-    if world > 1 and a.exchange == "auto" and trainer.exchange == "p2p" and \
-            (not replicas_agree(model, trainer) or os.environ.get("BSAREC_P2P_FORCE_RERUN") == "1"):     # (env: rehearsal)
-        # never seen on the hardware this was written on (one GPU); on a node where the peer-to-peer exchange misbehaves the
-        # measurement is repeated through RCCL rather than lost
-        p2p_rerun = "peer-to-peer exchange left the replicas different (or a wait timed out): measured again through RCCL"
-        if rank == 0:
-            print("bench: " + p2p_rerun, file=sys.stderr)
-        del feed, trainer, model, batches
-        model, batches, trainer = build("rccl")
-        use_graph = trainer.use_graph
-        feed = Feed(trainer, batches, dev)
-        stream = stream_batches()
-        model.train()
-        dt, loss = timed(feed, a.steps, a.warmup)
+    if world > 1 and a.exchange == "auto" and trainer.exchange == "p2p":
+        agree, cs_lo, cs_hi, timed_out = replicas_state(model, trainer)
+        forced = os.environ.get("BSAREC_P2P_FORCE_RERUN") == "1"        # rehearsal of this path on a healthy run
+        if not agree or forced:
+            # never seen on the hardware this was written on (one GPU); on a node where the peer-to-peer exchange misbehaves the
+            # measurement is repeated through RCCL rather than lost -- and the line says WHY it was repeated
+            if not agree:
+                why = ("a cross-GPU barrier wait timed out" if timed_out else "the replicas' parameter checksums differ") + \
+                      f" (lowest {cs_lo!r}, highest {cs_hi!r} over the ranks)"
+                p2p_rerun = {"reason": "divergence", "detail": why, "forced": False}
+            else:
+                p2p_rerun = {"reason": "forced", "detail": "BSAREC_P2P_FORCE_RERUN=1 (rehearsal; the replicas agreed: "
+                                                           f"checksum {cs_lo!r} on every rank)", "forced": True}
+            p2p_rerun["action"] = "measured again through RCCL"
+            if rank == 0:
+                print(f"bench: peer-to-peer run repeated through RCCL -- {p2p_rerun['reason']}: {p2p_rerun['detail']}", file=sys.stderr)
+            del feed, trainer, model, batches
+            model, batches, trainer = build("rccl")
+            use_graph = trainer.use_graph
+            feed = Feed(trainer, batches, dev)
+            stream = stream_batches()
+            model.train()
+            dt, loss = timed(feed, a.steps, a.warmup)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

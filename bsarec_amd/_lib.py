@@ -144,6 +144,8 @@ EXPORTS = {
     "bsarec_grad_step_indexed": (C.c_int, [C.c_void_p] * 4 + [C.c_long] + [C.c_void_p] * 3 + [C.c_float] * 3 + [C.c_void_p]),
     "bsarec_adam_apply": (C.c_int, [C.POINTER(Adam), C.c_void_p, C.c_void_p]),
     "bsarec_mask_seen": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_topk_seen": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
     "bsarec_freq_layer_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_int,
                                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_freq_layer_bwd_scratch_floats": (C.c_long, [C.c_int, C.c_int, C.c_int]),

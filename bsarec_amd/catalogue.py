@@ -227,7 +227,7 @@ class ShardedCatalogue:
         cand_v = torch.full((Bg, k), -float("inf"), device=self.device)
         cand_i = torch.zeros(Bg, k, dtype=torch.int64, device=self.device)
         if self.Vs:
-            v, i = torch.topk(scores, kk, dim=1)
+            v, i = self._topk_rows(scores, self.logits.stride(0), kk)
             cand_v[:, :kk], cand_i[:, :kk] = v, i + self.lo
         all_v = torch.empty(W, Bg, k, device=self.device)
         all_i = torch.empty(W, Bg, k, dtype=torch.int64, device=self.device)
@@ -235,10 +235,45 @@ class ShardedCatalogue:
         dist.all_gather(list(all_i.unbind(0)), cand_i, group=g)
         mv = all_v.permute(1, 0, 2).reshape(Bg, W * k)
         mi = all_i.permute(1, 0, 2).reshape(Bg, W * k)
-        top_v, sel = torch.topk(mv, k, dim=1)
+        top_v, sel = self._topk_rows(mv.contiguous(), W * k, k)
         top_i = torch.gather(mi, 1, sel)
         r0 = self.rank * B
         return top_v[r0:r0 + B].clone(), top_i[r0:r0 + B].clone()
+
+    def _topk_rows(self, scores, ld, k):
+        """k best columns of every row, descending (``bsarec_topk_seen`` without a seen-item mask: the HIP top-k of the
+        evaluation path; equal scores go to the smaller column)."""
+        rows, V = scores.shape[0], scores.shape[1]
+        idx = torch.empty(rows, k, dtype=torch.int64, device=self.device)
+        val = torch.empty(rows, k, dtype=torch.float32, device=self.device)
+        L.check(self.lib.bsarec_topk_seen(scores.data_ptr(), ld, rows, V, None, None, None, k, idx.data_ptr(), val.data_ptr(),
+                                          self.encoder._stream()), "bsarec_topk_seen")
+        return val, idx
+
+    @torch.no_grad()
+    def full_sort_scores(self, batches, epoch: int = 0, k: int = 20):
+        """The reference's evaluation bookkeeping (src/trainers.py:118-158 + get_full_sort_score, :70-83) over the SHARDED
+        table: ``batches`` yields this rank's (input_ids [B, L], answers [B], seen [B, S] or None) per step (every rank the
+        same number of steps); the top-20 of each sequence comes from :meth:`topk`, hits and DCG sums are all-reduced, so
+        every rank returns the metrics of the GLOBAL evaluation set: ([HR@5, NDCG@5, HR@10, NDCG@10, HR@20, NDCG@20], str)."""
+        import torch.distributed as dist
+        from .trainer import ndcg_at_k, recall_at_k
+        ks = (5, 10, 20)
+        sums = torch.zeros(2 * len(ks) + 1, dtype=torch.float64, device=self.device)
+        for ids, answers, seen in batches:
+            _, top_i = self.topk(ids, k=k, seen=seen)
+            hit = top_i == answers.to(device=self.device, dtype=torch.int64).view(-1, 1)
+            n = hit.shape[0]
+            for j, kk in enumerate(ks):
+                sums[2 * j] += recall_at_k(hit, kk) * n
+                sums[2 * j + 1] += ndcg_at_k(hit, kk) * n
+            sums[-1] += n
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        vals = (sums[:-1] / sums[-1].clamp(min=1)).tolist()
+        post_fix = {"Epoch": epoch, "HR@5": '{:.4f}'.format(vals[0]), "NDCG@5": '{:.4f}'.format(vals[1]),
+                    "HR@10": '{:.4f}'.format(vals[2]), "NDCG@10": '{:.4f}'.format(vals[3]),
+                    "HR@20": '{:.4f}'.format(vals[4]), "NDCG@20": '{:.4f}'.format(vals[5])}
+        return vals, str(post_fix)
 
     def close(self):
         torch.cuda.synchronize(self.device)

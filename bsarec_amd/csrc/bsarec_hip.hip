@@ -528,6 +528,27 @@ static int launch_freq_bwd(const float* X, const float* dF, const float* dXin, c
 
 static bool fused_ok(const bsarec_plan& p) { return p.fused; }
 
+// Host-side check of everything a direct (buffer-descriptor) kernel is about to dereference.  These kernels prefetch
+// without predicates and rely on the descriptor's range check; a descriptor whose BASE is null with a non-zero range
+// reads virtual address 0 + offset -- a memory fault (which on this pool can reset the node), not a wrong number.
+// Round 2 saw exactly such a fault ("address (nil)") from an experimental 8-wave variant of the logits backward whose
+// source was not kept; whatever its cause was, a launch with a null or oversized operand is now refused here
+// (return < 0, nothing enqueued) instead of being found by the GPU.
+static bool dw_problem_ok(const DwProblem& q) {
+    if (!q.A || !q.B || !q.slab) return false;
+    if (q.K < 1 || q.M < 1 || q.N < 1 || q.kchunk < 8 || (q.kchunk & 7) || q.nslab < 1) return false;
+    if (q.lda < q.M || q.ldb < q.N) return false;
+    const long esz = q.bf16 ? 2 : 4;
+    if (((long)(q.K - 1) * q.lda + q.M) * esz >= (1L << 31) || ((long)(q.K - 1) * q.ldb + q.N) * esz >= (1L << 31)) return false;
+    return true;
+}
+static bool dh_problem_ok(const DhP& h) {
+    if (!h.A || !h.E || !h.slab) return false;
+    if (h.B < 1 || h.V < 1 || h.kchunk < 8 || (h.kchunk & 7) || h.nsplit < 1 || h.lda < h.V) return false;
+    if ((long)h.B * h.lda * 4 >= (1L << 31) || (long)h.V * 256 >= (1L << 31)) return false;
+    return true;
+}
+
 static void fill_top_fwd(bsarec_plan& p, int l, bool tr, TopFwdP& F);
 
 static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const int64_t* ids = nullptr, const GatherP* gp = nullptr,
@@ -967,6 +988,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
         H.A = p->dlogits; H.lda = p->Vp; H.E = p->P.item_emb; H.B = B; H.V = c.item_size; H.kchunk = p->vchunk;
         H.nsplit = p->vsplit; H.slab = p->dlast_slab;
         const int tiles = cdiv(c.item_size, 64);
+        if (!dw_problem_ok(q) || !dh_problem_ok(H)) return -21;
         LAUNCH(logits_bwd_direct_kernel, dim3(tiles + cdiv(cdiv(B, 32) * p->vsplit, 4)), dim3(256), 0, s, q, tiles, H);
         HIPCHK(hipGetLastError());
     } else
@@ -1194,6 +1216,8 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                         sc.de = p->dz; sc.ids32 = p->ids32; sc.T = T; sc.dE = p->lookup_grad ? p->lookup_grad : p->G.item_emb;
                         sc.nblocks = cdiv(T, SCATTER_FLOATS / 64);
                     }
+                    for (int i = 0; i < dw_np; ++i) if (!dw_problem_ok(DW.P[i])) return -21;
+                    if (sc.nblocks && (!sc.de || !sc.ids32 || !sc.dE)) return -21;
                     ProfScope prof(BSAREC_K_DW1, s);
                     LAUNCH(dw_direct_kernel, dim3(8 * cdiv(ns, 8) * (dw_nu - DW.nsmall) + DW.nsmall * DW.small_slabs + sc.nblocks +
                                                   (tk_here.state ? 1 : 0)), dim3(256), 0, s, DW, tk_here, sc);
@@ -1367,6 +1391,15 @@ extern "C" int bsarec_mask_seen(float* scores, long ld, int B, const int64_t* us
                                 const int64_t* indices, void* stream) {
     if (!scores || !users || !indptr || !indices || B < 1 || ld < 1) return -10;
     hipLaunchKernelGGL(mask_seen_kernel, dim3(B), dim3(ROW_THREADS), 0, (hipStream_t)stream, scores, ld, users, indptr, indices);
+    return (int)hipGetLastError();
+}
+
+extern "C" int bsarec_topk_seen(float* scores, long ld, int B, int V, const int64_t* users, const int64_t* indptr,
+                                const int64_t* indices, int k, int64_t* out_idx, float* out_val, void* stream) {
+    if (!scores || !out_idx || B < 1 || V < 1 || ld < V || k < 1 || k > TOPK_MAX || k > V) return -10;
+    if (indptr && (!users || !indices)) return -10;
+    hipLaunchKernelGGL(topk_seen_kernel, dim3(B), dim3(ROW_THREADS), 0, (hipStream_t)stream, scores, ld, V, users, indptr, indices, k,
+                       out_idx, out_val);
     return (int)hipGetLastError();
 }
 

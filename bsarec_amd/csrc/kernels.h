@@ -892,3 +892,58 @@ mask_seen_kernel(float* __restrict__ scores, long ld, const int64_t* __restrict_
     float* row = scores + (long)blockIdx.x * ld;
     for (long j = j0 + threadIdx.x; j < j1; j += ROW_THREADS) row[indices[j]] = 0.f;
 }
+
+// Top-k of every score row with the seen items zeroed first: the body of the reference's evaluation loop for one batch
+// (src/trainers.py:134-149: rating_pred[train_matrix[user] > 0] = 0, np.argpartition(..., -20), argsort of the 20) in ONE
+// launch, one workgroup per user.  (1) the CSR row of the user is written as zeros into the score row (as the reference
+// does -- the caller may still read the masked scores); (2) every thread keeps the best k of its strided share of the row
+// as a sorted list in LDS (one compare rejects almost every candidate); (3) k rounds of a workgroup arg-max over the 256
+// list heads produce the result in descending order.  Ties (exact equal scores, e.g. the zeros of seen items when fewer
+// than k scores are positive) go to the smaller item id; the reference's argpartition leaves their order unspecified and
+// they cannot change HR / NDCG (the answer is never a seen item).  k <= TOPK_MAX (48 KB of list storage in LDS).
+#define TOPK_MAX 24
+__device__ __forceinline__ bool topk_better(float v, long i, float w, long j) { return v > w || (v == w && i < j); }
+__global__ void __launch_bounds__(ROW_THREADS)
+topk_seen_kernel(float* __restrict__ scores, long ld, int V, const int64_t* __restrict__ users, const int64_t* __restrict__ indptr,
+                 const int64_t* __restrict__ indices, int k, int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    __shared__ float lv[TOPK_MAX][ROW_THREADS];          // [rank][thread]: conflict-free for "every thread touches its rank r"
+    __shared__ int li[TOPK_MAX][ROW_THREADS];
+    __shared__ float rv[ROW_THREADS / 64];
+    __shared__ int ri[ROW_THREADS / 64], rt[ROW_THREADS / 64];
+    const int tid = threadIdx.x;
+    float* row = scores + (long)blockIdx.x * ld;
+    if (indptr) {
+        const long u = users[blockIdx.x];
+        const long j0 = indptr[u], j1 = indptr[u + 1];
+        for (long j = j0 + tid; j < j1; j += ROW_THREADS) { const long it = indices[j]; if (it >= 0 && it < V) row[it] = 0.f; }
+        __syncthreads();                                 // (drains the stores: the scan below reads the zeros)
+    }
+    for (int r = 0; r < k; ++r) { lv[r][tid] = -INFINITY; li[r][tid] = 0x7fffffff; }
+    float vmin = -INFINITY; int imin = 0x7fffffff;       // this thread's current k-th best
+    for (int j = tid; j < V; j += ROW_THREADS) {
+        const float v = row[j];
+        if (!topk_better(v, j, vmin, imin)) continue;
+        int r = k - 1;                                   // insertion into the sorted list (descending)
+        while (r > 0 && topk_better(v, j, lv[r - 1][tid], li[r - 1][tid])) { lv[r][tid] = lv[r - 1][tid]; li[r][tid] = li[r - 1][tid]; --r; }
+        lv[r][tid] = v; li[r][tid] = j;
+        vmin = lv[k - 1][tid]; imin = li[k - 1][tid];
+    }
+    int head = 0;                                        // next unused rank of this thread's list
+    for (int r = 0; r < k; ++r) {
+        float v = head < k ? lv[head][tid] : -INFINITY;
+        int i = head < k ? li[head][tid] : 0x7fffffff, t = tid;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {        // wave arg-max (value desc, item id asc)
+            const float v2 = __shfl_xor(v, off, 64); const int i2 = __shfl_xor(i, off, 64), t2 = __shfl_xor(t, off, 64);
+            if (topk_better(v2, i2, v, i)) { v = v2; i = i2; t = t2; }
+        }
+        if ((tid & 63) == 0) { rv[tid >> 6] = v; ri[tid >> 6] = i; rt[tid >> 6] = t; }
+        __syncthreads();
+        float bv = rv[0]; int bi = ri[0], bt = rt[0];
+#pragma unroll
+        for (int w = 1; w < ROW_THREADS / 64; ++w) if (topk_better(rv[w], ri[w], bv, bi)) { bv = rv[w]; bi = ri[w]; bt = rt[w]; }
+        if (tid == bt) ++head;
+        if (tid == 0) { out_idx[(long)blockIdx.x * k + r] = bi; if (out_val) out_val[(long)blockIdx.x * k + r] = bv; }
+        __syncthreads();
+    }
+}

@@ -521,16 +521,16 @@ class Trainer:
 
     def topk_after_seen(self, user_ids, input_ids, k: int = 20, return_scores: bool = False):
         """The body of the reference's eval loop for one batch (src/trainers.py:126-149): full-catalogue scores of the
-        last position (HIP), seen items := 0 -- not -inf -- (one HIP launch over the device CSR, no host round trip),
-        top-k ids in descending score order."""
+        last position (HIP), then ONE launch that sets the seen items' scores to 0 -- not -inf -- from the device CSR and
+        takes the k best ids in descending score order (``bsarec_topk_seen``; no host round trip, no torch.topk)."""
         from . import _lib as L
         scores = self.model.full_logits(input_ids).clone()           # a copy: the plan's logits buffer stays intact
         indptr, indices = self._seen_csr()
         users = user_ids.to(device=self.device, dtype=torch.int64).contiguous()
-        L.check(L.load().bsarec_mask_seen(scores.data_ptr(), scores.stride(0), scores.shape[0], users.data_ptr(),
-                                          indptr.data_ptr(), indices.data_ptr(),
-                                          torch.cuda.current_stream(self.device).cuda_stream), "bsarec_mask_seen")
-        pred = torch.topk(scores, k, dim=1).indices
+        pred = torch.empty(scores.shape[0], k, dtype=torch.int64, device=self.device)
+        L.check(L.load().bsarec_topk_seen(scores.data_ptr(), scores.stride(0), scores.shape[0], scores.shape[1], users.data_ptr(),
+                                          indptr.data_ptr(), indices.data_ptr(), k, pred.data_ptr(), None,
+                                          torch.cuda.current_stream(self.device).cuda_stream), "bsarec_topk_seen")
         return (pred, scores) if return_scores else pred
 
     def _seen_csr(self):

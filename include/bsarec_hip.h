@@ -246,6 +246,13 @@ int bsarec_grad_step_indexed(bsarec_plan_t *plan, const int64_t *table, const in
 int bsarec_mask_seen(float *scores, long ld, int B, const int64_t *users, const int64_t *indptr,
                      const int64_t *indices, void *stream);
 
+/* The same masking AND the reference's top-k (src/trainers.py:134-149: argpartition of the 20 best + argsort) in one
+ * launch, one workgroup per user: scores[b][seen items] = 0, then out_idx[b][0..k) = item ids of the k largest scores of
+ * scores[b][0..V) in descending order (equal scores: smaller id first), out_val (nullable) their scores.  indptr == NULL:
+ * no masking.  k <= 24, k <= V <= ld. */
+int bsarec_topk_seen(float *scores, long ld, int B, int V, const int64_t *users, const int64_t *indptr,
+                     const int64_t *indices, int k, int64_t *out_idx, float *out_val, void *stream);
+
 /* Stand-alone FrequencyLayer (src/model/bsarec.py:90-104) for per-op parity tests:
  * y = LN(Drop(low + beta^2 (x - low)) + x); backward given dy. */
 int bsarec_freq_layer_fwd(const float *x, const float *sqrt_beta, const float *ln_w, const float *ln_b,

@@ -271,3 +271,36 @@ def test_bench_command_of_the_driver_builds_no_graph_on_the_clock():
     bad = (arena_g - tr2.model._arena).abs() > 5e-5
     print("graph vs eager after", ran, "steps: fraction off", bad.float().mean().item())
     assert bad.float().mean().item() <= 1e-2
+
+
+@pytest.mark.parametrize("V,B,k", [(3417, 64, 20), (20034, 33, 20), (40, 5, 20), (100003, 3, 10)])
+def test_hip_topk_with_seen_mask_equals_torch(V, B, k):
+    """bsarec_topk_seen (the reference's `rating_pred[seen] = 0` + argpartition / argsort of the 20 best, src/trainers.py:134-149,
+    as one HIP launch): same item lists and scores as zeroing + torch.topk; equal scores (the zeros) go to the smaller id."""
+    from bsarec_amd import _lib as Lb
+    lib = Lb.load()
+    g = torch.Generator(device="cuda").manual_seed(V)
+    scores = torch.randn(B, V, device="cuda", generator=g)
+    rng = np.random.default_rng(V)
+    rows = [np.unique(rng.integers(0, V, size=int(rng.integers(0, min(V, 400))))) for _ in range(B + 3)]
+    indptr = torch.as_tensor(np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64), device="cuda")
+    indices = torch.as_tensor(np.concatenate(rows).astype(np.int64), device="cuda")
+    users = torch.as_tensor(rng.permutation(B + 3)[:B].astype(np.int64), device="cuda")
+    want = scores.clone()
+    for b in range(B):
+        u = int(users[b])
+        want[b, indices[int(indptr[u]):int(indptr[u + 1])]] = 0.0
+    got_idx = torch.empty(B, k, dtype=torch.int64, device="cuda")
+    got_val = torch.empty(B, k, dtype=torch.float32, device="cuda")
+    work = scores.clone()
+    Lb.check(lib.bsarec_topk_seen(work.data_ptr(), work.stride(0), B, V, users.data_ptr(), indptr.data_ptr(), indices.data_ptr(), k,
+                                  got_idx.data_ptr(), got_val.data_ptr(), torch.cuda.current_stream().cuda_stream), "bsarec_topk_seen")
+    torch.cuda.synchronize()
+    assert torch.equal(work, want)                                   # the masked scores are what the reference would hold
+    # reference order: value descending, ties (the zeros) by item id ascending
+    key = torch.argsort(torch.arange(V, device="cuda").expand(B, V), dim=1, stable=True)
+    order = torch.sort(want, dim=1, descending=True, stable=True).indices     # stable: equal scores keep ascending id order
+    assert torch.equal(got_idx, order[:, :k])
+    assert torch.equal(got_val, torch.gather(want, 1, order[:, :k]))
+    tv = torch.topk(want, k, dim=1).values
+    assert torch.equal(got_val, tv)

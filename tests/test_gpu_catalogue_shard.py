@@ -166,7 +166,19 @@ def _worker(rank, world, port, kw, out_dir):
         ids, _ = _batches(ns, 1, world * B)[0]
         seen = _seen(ns, world * B)
         tv, ti = sc.topk(ids[rank * B:(rank + 1) * B], 20, seen[rank * B:(rank + 1) * B])
-        np.savez(os.path.join(out_dir, f"topk{rank}.npz"), v=tv.cpu().numpy(), i=ti.cpu().numpy())
+        # HR / NDCG bookkeeping over the sharded table (answers = each sequence's own best unseen item -> HR@5 = 1, and a second
+        # set of answers that nobody ranks: item 0 is seen-or-low): every rank must report the GLOBAL metrics
+        mine = slice(rank * B, (rank + 1) * B)
+        ans_hit = ti[:, 2].clone()                                   # rank 2 of every list: HR@5/10/20 = 1, NDCG = 1/log2(4) = 0.5
+        vals, txt = sc.full_sort_scores([(ids[mine], ans_hit, seen[mine])], epoch=3)
+        assert vals[0] == 1.0 and vals[2] == 1.0 and vals[4] == 1.0 and abs(vals[1] - 0.5) < 1e-12 and abs(vals[5] - 0.5) < 1e-12, vals
+        assert txt.startswith("{'Epoch': 3, 'HR@5': '1.0000', 'NDCG@5': '0.5000'")
+        ans_mixed = torch.where(torch.arange(B, device=ti.device) % 2 == 0, ti[:, 0], ti[:, 19])      # even rows best item, odd rows the 20th
+        if rank % 2 == 1:
+            ans_mixed = ti[:, 7]                                     # odd ranks: 8th place -> in HR@10 / HR@20 only
+        vals2, _ = sc.full_sort_scores([(ids[mine], ans_mixed, seen[mine])])
+        np.savez(os.path.join(out_dir, f"topk{rank}.npz"), v=tv.cpu().numpy(), i=ti.cpu().numpy(), vals2=np.asarray(vals2),
+                 ans_mixed=ans_mixed.cpu().numpy())
         sd = {k: v.detach().cpu().numpy() for k, v in sc.full_state_dict().items()}
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), losses=np.asarray(losses), **sd)
         sc.close()
@@ -212,6 +224,16 @@ def test_ranks_sharded_catalogue_equals_the_full_table_step(world, kw, tmp_path)
         wv, wi = want_v[r * B:(r + 1) * B].cpu().numpy(), want_i[r * B:(r + 1) * B].cpu().numpy()
         np.testing.assert_allclose(t["v"], wv, rtol=1e-5, atol=1e-6)
         assert (t["i"] == wi).mean() > 0.99                       # (equal scores may swap places)
+    # the metric bookkeeping: every rank reported the same numbers, and they are the reference's formulas (src/metrics.py:3-31)
+    # over ALL ranks' sequences
+    allv = [np.load(tmp_path / f"topk{r}.npz")["vals2"] for r in range(world)]
+    for v in allv[1:]:
+        np.testing.assert_array_equal(allv[0], v)
+    hits = np.concatenate([np.load(tmp_path / f"topk{r}.npz")["i"] == np.load(tmp_path / f"topk{r}.npz")["ans_mixed"][:, None] for r in range(world)])
+    want_m = []
+    for kk in (5, 10, 20):
+        want_m += [hits[:, :kk].any(1).mean(), (hits[:, :kk] / np.log2(np.arange(kk) + 2.0)).sum(1).mean()]
+    np.testing.assert_allclose(allv[0], want_m, rtol=1e-12, atol=1e-12)
     sd = model.state_dict()
     assert set(sd) == set(r0.files) - {"losses"}
     for k in sd:

@@ -292,3 +292,54 @@ def test_bench_timed_region_builds_no_graph():
     assert tr.calls == ["prepare", 5, 20] and dt >= 0
     with pytest.raises(AssertionError, match="captured inside the timed region"):
         bench.timed_steps(bench.Feed(FakeTrainer(lazy=True), Bt(), "cpu"), 20, 5, lambda: None)
+
+
+def _disassemble_gfx950(tmp_path):
+    """The gfx950 code object inside libbsarec_hip.so, disassembled (llvm tools of the ROCm install)."""
+    import shutil
+    import subprocess
+    from bsarec_amd import _lib
+    _lib.load()
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm llvm tools not found")
+    so = os.path.join(ROOT, "bsarec_amd", "libbsarec_hip.so")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([tools[0], f"--dump-section=.hip_fatbin={fat}", so, str(tmp_path / "stripped.so")])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           f"--output={co}"])
+    return subprocess.check_output([tools[2], "-d", "--no-show-raw-insn", co], text=True)
+
+
+def _kernel_body(dis, mangled_prefix):
+    m = re.search(r"^[0-9a-f]+ <(" + re.escape(mangled_prefix) + r"[^>]*)>:\n(.*?)s_endpgm", dis, re.S | re.M)
+    assert m, f"{mangled_prefix} not found in the code object"
+    return [ln.split("//")[0].strip() for ln in m.group(2).splitlines() if ln.strip()]
+
+
+def test_p2p_exchange_isa_carries_system_scope(tmp_path):
+    """The peer-to-peer gradient exchange (csrc/comm.h, adam_kernel in csrc/kernels.h) has only ever run with both ranks on
+    ONE GPU, where a missing scope bit cannot show (one L2).  What the 2-rank rehearsal cannot see the ISA can:
+      * comm_barrier_kernel: a system-scope write-back (buffer_wbl2 sc0 sc1) that is WAITED for (s_waitcnt vmcnt(0)) comes
+        before the first flag store, the flag store itself and the polling load carry sc0 sc1 (system scope: the flags
+        live in a peer GPU's memory), and a system-scope invalidate follows the poll;
+      * adam_kernel: the peer arenas are read with sc0 sc1 loads (no cache of the reading GPU may serve a stale line)."""
+    dis = _disassemble_gfx950(tmp_path)
+    k = _kernel_body(dis, "_Z19comm_barrier_kernel")
+    stores = [i for i, ln in enumerate(k) if ln.startswith("global_store_dwordx2") and "sc0 sc1" in ln]
+    assert stores, "no system-scope flag store in comm_barrier_kernel"
+    first = stores[0]
+    wb = [i for i, ln in enumerate(k[:first]) if ln.startswith("buffer_wbl2") and "sc0 sc1" in ln]
+    assert wb, "no system-scope write-back before the flag store"
+    assert any("s_waitcnt" in ln and "vmcnt(0)" in ln for ln in k[wb[0]:first]), \
+        "the write-back before the flag store is not waited for (the flag could overtake it)"
+    # every store to a peer's flag word is system scope: no plain global_store after the first release
+    assert not [ln for ln in k[first:] if ln.startswith("global_store") and "sc0 sc1" not in ln]
+    polls = [i for i, ln in enumerate(k) if ln.startswith("global_load_dwordx2") and "sc0 sc1" in ln and i > first]
+    assert polls, "the flag poll is not a system-scope load"
+    assert any(ln.startswith("buffer_inv") and "sc0 sc1" in ln for ln in k[polls[0]:]), "no system-scope invalidate behind the poll"
+    assert any(ln.startswith("s_sleep") for ln in k), "the poll loop does not back off"
+    a = _kernel_body(dis, "_Z11adam_kernel")
+    remote = [ln for ln in a if ln.startswith("global_load_dwordx2") and "sc0 sc1" in ln]
+    assert len(remote) >= 2, "adam_kernel does not read the peer arenas with system-scope loads"
