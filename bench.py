@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse headline)
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_C1.csv")     # committed rocprofv3 --pmc passes of this round's library
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_C1.csv")     # committed rocprofv3 --pmc passes of this round's library
 
 
 def model_args(a):
@@ -568,6 +568,34 @@ def main():
                 return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, src
             return None, None
         traffic, tsrc = pmc_traffic(top["kernel"].split(" ")[0].split("<")[0])
+
+        def fp32_alu_share(kernel_prefix, avg_us):
+            """On the fp32 path an MFMA occupies the SIMD's vector ALU: while v_mfma_f32_{16x16x4,32x32x2}_f32 executes, no
+            vector instruction of either resident wave issues (tools/micro/mfma_valu_mix.hip -> profiles/r03_micro_mfma_valu_mix.txt;
+            a bf16 MFMA does not do that).  So the fp32 kernels' ALU time is MFMA cycles + VALU cycles, ADDITIVE, and the MFMA
+            peak alone is not reachable by a kernel that also has vector work.  From the committed PMC passes: cycles per
+            SIMD spent in MFMAs (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) + in other vector instructions
+            ((SQ_INSTS_VALU - SQ_INSTS_MFMA) / 1024 x 2.2 cycles, the measured two-waves-per-SIMD issue rate), against the
+            launch's duration at the 2.4 GHz maximum clock (a lower bound of the busy fraction: the chip clocks lower under load)."""
+            path = os.path.join(ROOT, PMC_PROFILE)
+            if not os.path.exists(path) or not fused or a.batch != 256 or a.dtype != "f32":
+                return None
+            vals = {}
+            for line in open(path):
+                if line.startswith('"' + kernel_prefix):
+                    _, counter, avg, _ = line.rsplit(",", 3)
+                    vals[counter] = float(avg)
+            need = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA")
+            if not all(k in vals for k in need):
+                return None
+            mfma_cyc = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0
+            valu_cyc = (vals["SQ_INSTS_VALU"] - vals["SQ_INSTS_MFMA"]) / 1024.0 * 2.2
+            avail = avg_us * 1e-6 * 2.4e9
+            return {"mfma_cycles_per_simd": round(mfma_cyc), "valu_cycles_per_simd": round(valu_cyc),
+                    "launch_cycles_at_2.4GHz": round(avail), "busy_frac": round((mfma_cyc + valu_cyc) / avail, 4),
+                    "mfma_only_frac": round(mfma_cyc / avail, 4),
+                    "note": "fp32 MFMA and VALU share the SIMD's ALU (micro-benchmark in tools/micro/): busy = MFMA + VALU cycles"}
+        alu = fp32_alu_share(top["kernel"].split(" ")[0].split("<")[0], top["avg_us"])
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"],
                            "peak": peak, "unit": "TFLOP/s",
                            "frac": round(top["achieved"] / peak, 5),
@@ -575,7 +603,7 @@ def main():
                                             "the blocks the launch stands for",
                            "algorithmic_achieved": top.get("algorithmic_achieved"),
                            "algorithmic_frac": round(top["algorithmic_achieved"] / peak, 5) if top.get("algorithmic_achieved") else None,
-                           "traffic": traffic, "traffic_source": tsrc,
+                           "traffic": traffic, "traffic_source": tsrc, "fp32_alu": alu,
                            "avg_us": top["avg_us"], "event_overhead_us": round(ovh_s * 1e6, 3), "launches_per_step": top["launches_per_step"],
                            "flops_per_launch": top["flops_per_launch"], "other_kernels": rows[1:]}
 

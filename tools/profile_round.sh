@@ -1,7 +1,8 @@
 #!/bin/bash
 # End-of-round measurement on the GPU box: kernel trace + PMC passes + the bench line (fp32 headline; bf16 when asked).
-#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02 [bf16]'
-TAG=${1:-r02_x}
+#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r03 [bf16]'
+TAG=${1:-r03_x}
+RND=${TAG%%_*}
 DT=${2:-f32}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -23,6 +24,8 @@ find $OUT/trace -name '*.csv' ! -name '*stats*' -delete; find $OUT -size +8M -de
 python3 tools/prof_summary.py $OUT/kernel_stats.csv 220 20
 cat $OUT/timeline.txt
 # the bench line's roofline.traffic comes from the PMC passes of THIS build (same library_sha16)
-if [ "$DT" = f32 ]; then cp $OUT/pmc.csv $R/profiles/r02_pmc_C1.csv; fi
+if [ "$DT" = f32 ]; then cp $OUT/pmc.csv $R/profiles/${RND}_pmc_C1.csv; fi
 timeout -k 10 300 python3 bench.py --dtype $DT > $OUT/bench_line.json 2> $OUT/bench.err
 cat $OUT/bench_line.json
+# ... and the driver's own command line (BENCH_rNN.json): short run, every graph built before the clock
+if [ "$DT" = f32 ]; then timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line_driver_cmd.json 2>> $OUT/bench.err; cut -c1-260 $OUT/bench_line_driver_cmd.json; fi
