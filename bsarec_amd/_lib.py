@@ -136,6 +136,7 @@ EXPORTS = {
     "bsarec_logits": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_backward_seq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bsarec_backward_seq_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bsarec_adam_step": (C.c_int, [C.POINTER(Adam), C.c_void_p, C.c_void_p]),
     "bsarec_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Adam), C.c_void_p]),
     "bsarec_gather_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int,

@@ -141,6 +141,7 @@ struct bsarec_plan {
     bool pruned;                               // mode of the last forward
     int loss_kind;                             // head of the last loss call: 0 = full-catalogue CE, 1 = SASRec's BCE pair
     const float* ext_dy = nullptr;             // bsarec_backward_seq: upstream gradient of the last layer's output, all positions
+    const float* ext_mid[BSAREC_MAX_LAYERS] = {};   // bsarec_backward_seq_multi: upstream gradients of layer outputs 0 .. N-1 (null: none)
     const int64_t *bce_pos, *bce_neg;
     float *part_kvb, *slab_dummy;
     float* part_cwL[BSAREC_MAX_LAYERS];        // FMLPRec: per-sequence d(complex_weight) [B][cb][d][2]
@@ -633,6 +634,7 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     if (l == 0) {       // the embedding front-end's backward (Drop + LayerNorm) rides in the bottom block's epilogue
         F.e_dz = p.dz; F.e_xhat = p.xhat0; F.e_rstd = p.rstd0; F.e_g = p.P.ln_w;
         F.e_pg = p.part_ln0; F.e_pb = p.part_ln0 + nb * d; F.e_drop = make_drop(p, c.p_hidden, 0, tr);
+        F.e_dx_extra = p.ext_dy ? p.ext_mid[0] : nullptr;
     }
     F.dT = p.dT; F.dU = p.dU; F.dO = p.dO; F.dq = p.dq; F.dk = p.dk; F.dv = p.dv;
     F.pg_ff = p.part_ln + 0 * nb * d; F.pb_ff = p.part_ln + 1 * nb * d; F.pg_a = p.part_ln + 2 * nb * d;
@@ -941,6 +943,18 @@ extern "C" int bsarec_backward_seq(bsarec_plan_t* p, const float* d_out, void* s
     return rc;
 }
 
+extern "C" int bsarec_backward_seq_multi(bsarec_plan_t* p, const float* const* d_outs, void* stream) {
+    if (!p || !d_outs) return -10;
+    const int N = p->cfg.layers;
+    if (!d_outs[N]) return -10;                // the last layer's gradient is always given (zeros if the caller has none)
+    if (p->pruned) return -13;                 // the forward kept only the last row of the top block: run bsarec_forward
+    for (int l = 0; l < N; ++l) p->ext_mid[l] = d_outs[l];
+    const int rc = bsarec_backward_seq(p, d_outs[N], stream);
+    for (int l = 0; l < N; ++l) p->ext_mid[l] = nullptr;
+    return rc;
+}
+
+
 // Can the final gradient reduction and Adam be one launch (reduce_adam_kernel)?  Needs the direct weight-gradient
 // launch of block 0 to host the step tick, plain single-GPU gradient sources, and every gradient tensor inside the flat
 // arena the update walks (item table + the reduction jobs' targets = the whole arena).
@@ -1237,6 +1251,15 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                                                      dXout, p->part_beta, s, c.filter_kind == 1 ? w.filter_cw : nullptr,
                                                      c.filter_kind == 1 ? p->part_cwL[l] : nullptr)));
         dY = dXout;
+        // forward(all_sequence_output=True): layer output l may carry an upstream gradient of its own -- it joins the gradient
+        // coming down from the blocks above (the fused bottom block adds output 0's inside its epilogue: its dX never
+        // reaches memory)
+        if (p->ext_dy && p->ext_mid[l] && !(p->fused && l == 0)) {
+            const long n4 = (long)T * d / 4;
+            LAUNCH(grad_join_kernel, dim3((unsigned)std::min<long>(cdiv(n4, ROW_THREADS), 2048)), dim3(ROW_THREADS), 0, s, dXout,
+                   p->ext_mid[l], n4, p->bf ? 1 : 0);
+            HIPCHK(hipGetLastError());
+        }
     }
     // ---- embedding front-end backward
     {

@@ -857,6 +857,8 @@ struct FusedBwdP {
     // bottom block only (e_dz != null): the embedding front-end's backward rides in the epilogue --
     // y = Drop(LN(e)) (src/model/_abstract_model.py:14-24): de = LNbwd(dX * keep/(1-p)) -> e_dz instead of dX
     float* e_dz; const float *e_xhat, *e_rstd, *e_g; float *e_pg, *e_pb; DropP e_drop;
+    const float* e_dx_extra;      // bottom block, optional: an upstream gradient of the EMBEDDING output itself (fp32 [B, L, 64]),
+                                  // added to dX before the embedding LayerNorm backward (forward(all_sequence_output=True)[0])
 };
 
 
@@ -1479,6 +1481,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
         const float* const e_xhat = KARG(FusedBwdP, e_xhat);
         const float* const e_rstd = KARG(FusedBwdP, e_rstd);
         const DropP e_drop = KARG(FusedBwdP, e_drop);
+        const float* const e_dx_extra = KARG(FusedBwdP, e_dx_extra);
         f32x4 g0 = {0, 0, 0, 0};
         if (e_dz) g0 = gld4(KARG(FusedBwdP, e_g) + lc);
 #pragma unroll
@@ -1493,6 +1496,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
                 const f32x4 lowx = lowpass_tab(spec, t, lc, L, cb, sTab);
                 const f32x4 lowg = lowpass_tab(spec + cb * 128, t, lc, L, cb, sTab);
                 dx = ld4(sG + t * FS + lc) + b2 * df + lowg;
+                if (e_dx_extra) dx += gld4(e_dx_extra + e);
                 sb += df * (xv - lowx);
                 if (e_dz) { xh = ald4<BF>(e_xhat, e); rs = gld(e_rstd + tok0 + t); dx = dx * drop_mult4(e_drop, dseed, (uint64_t)e >> 2); }
                 else ast4<BF>(R8_dX, e, dx);

@@ -893,6 +893,29 @@ mask_seen_kernel(float* __restrict__ scores, long ld, const int64_t* __restrict_
     for (long j = j0 + threadIdx.x; j < j1; j += ROW_THREADS) row[indices[j]] = 0.f;
 }
 
+// y += x on [n4 * 4] elements: the upstream gradient of an INTERMEDIATE layer output (forward(all_sequence_output=True),
+// src/model/bsarec.py:46-54) joins the gradient that flows down from the layers above.  y: the inter-block gradient
+// buffer (fp32, or bf16 under storage = 1), x: the caller's fp32 tensor.
+__global__ void __launch_bounds__(ROW_THREADS)
+grad_join_kernel(float* __restrict__ y, const float* __restrict__ x, long n4, int y_bf16) {
+    for (long i = (long)blockIdx.x * ROW_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * ROW_THREADS) {
+        const float4 b = reinterpret_cast<const float4*>(x)[i];
+        if (y_bf16) {
+            uint2 r = reinterpret_cast<uint2*>(y)[i];
+            const float a0 = __builtin_bit_cast(float, r.x << 16) + b.x, a1 = __builtin_bit_cast(float, r.x & 0xFFFF0000u) + b.y;
+            const float a2 = __builtin_bit_cast(float, r.y << 16) + b.z, a3 = __builtin_bit_cast(float, r.y & 0xFFFF0000u) + b.w;
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            const bf2 p0 = {(__bf16)a0, (__bf16)a1}, p1 = {(__bf16)a2, (__bf16)a3};
+            r.x = __builtin_bit_cast(unsigned, p0); r.y = __builtin_bit_cast(unsigned, p1);
+            reinterpret_cast<uint2*>(y)[i] = r;
+        } else {
+            float4 a = reinterpret_cast<float4*>(y)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            reinterpret_cast<float4*>(y)[i] = a;
+        }
+    }
+}
+
 // Top-k of every score row with the seen items zeroed first: the body of the reference's evaluation loop for one batch
 // (src/trainers.py:134-149: rating_pred[train_matrix[user] > 0] = 0, np.argpartition(..., -20), argsort of the 20) in ONE
 // launch, one workgroup per user.  (1) the CSR row of the user is written as zeros into the score row (as the reference

@@ -167,6 +167,39 @@ class _SeqFn(torch.autograd.Function):
         return (None, None) + model._grads_in_param_order(grads)
 
 
+class _SeqAllFn(torch.autograd.Function):
+    """BSARecModel.forward(all_sequence_output=True) as ONE autograd node with N + 1 outputs (src/model/bsarec.py:46-54: the
+    embedding output and every block's output): each element of the list carries gradients, as the reference's list does
+    -- ``bsarec_backward_seq_multi`` joins an intermediate output's upstream gradient with the one flowing down from above."""
+
+    @staticmethod
+    def forward(ctx, model, ids, *params):
+        B = ids.shape[0]
+        slot = 1
+        while (B, slot) in model._slots_busy:
+            slot += 1
+        model._slots_busy.add((B, slot))
+        ctx.token = _SlotToken(model, (B, slot))
+        plan = model._run_forward(ids, train=model.training, new_step=model.training, slot=slot)
+        ctx.model, ctx.plan = model, plan
+        N, Lq, d = model.args.num_hidden_layers, model.args.max_seq_length, model.args.hidden_size
+        return tuple(plan.view(L.BUF_LAYER_OUT, l, (B, Lq, d)).float().clone() for l in range(N + 1))
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        import ctypes as C
+        model, plan = ctx.model, ctx.plan
+        N = model.args.num_hidden_layers
+        gs = [None if g is None else g.to(torch.float32).contiguous() for g in gouts]
+        if gs[N] is None:
+            gs[N] = torch.zeros_like(next(g for g in gs if g is not None))
+        ptrs = (C.c_void_p * (N + 1))(*[None if g is None else g.data_ptr() for g in gs])
+        L.check(plan.lib.bsarec_backward_seq_multi(plan.handle, ptrs, model._stream()), "bsarec_backward_seq_multi")
+        grads = model._garena.clone()
+        ctx.token.release()
+        return (None, None) + model._grads_in_param_order(grads)
+
+
 class _LossFn(torch.autograd.Function):
     """calculate_loss as one autograd node: forward+loss kernels now, the whole backward chain when
     autograd calls back (src/trainers.py:103-106)."""
@@ -433,18 +466,15 @@ class BSARecModel(nn.Module):
 
     # ---- reference model API --------------------------------------------------------------------
     def forward(self, input_ids, user_ids=None, all_sequence_output=False):
-        """src/model/bsarec.py:16-28.  In train mode with autograd enabled the LAST layer's output is differentiable w.r.t. every
-        parameter (an autograd node over bsarec_forward / bsarec_backward_seq); the intermediate layer outputs of
-        ``all_sequence_output=True`` are returned detached.  :meth:`calculate_loss` stays the fast path of the trainer."""
+        """src/model/bsarec.py:16-28.  In train mode with autograd enabled the output is differentiable w.r.t. every parameter (an
+        autograd node over bsarec_forward / bsarec_backward_seq); with ``all_sequence_output=True`` EVERY element of the
+        returned list is (one node with N + 1 outputs, bsarec_backward_seq_multi), as in the reference where the whole list
+        is one autograd graph (bsarec.py:46-54).  :meth:`calculate_loss` stays the fast path of the trainer."""
         B, Lq, d = input_ids.shape[0], self.args.max_seq_length, self.args.hidden_size
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            last = _SeqFn.apply(self, input_ids, *self.parameters())
-            if not all_sequence_output:
-                return last
-            plan = last.grad_fn.plan if hasattr(last.grad_fn, "plan") else None
-            lower = [plan.view(L.BUF_LAYER_OUT, l, (B, Lq, d)).float().clone() for l in range(self.args.num_hidden_layers)] \
-                if plan is not None else []
-            return lower + [last]
+            if all_sequence_output:
+                return list(_SeqAllFn.apply(self, input_ids, *self.parameters()))
+            return _SeqFn.apply(self, input_ids, *self.parameters())
         plan = self._run_forward(input_ids, train=self.training, new_step=self.training)
         if all_sequence_output:
             return [plan.view(L.BUF_LAYER_OUT, l, (B, Lq, d)).float().clone() for l in range(self.args.num_hidden_layers + 1)]
@@ -636,15 +666,21 @@ class SASRecModel(BSARecModel):
         self._run_loss_bce(plan, answers, neg_answers)
         return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
 
+    def grad_step(self, input_ids, answers, neg_answers=None) -> torch.Tensor:
+        """step_begin + forward + BCE head + backward into the gradient arena (the data-parallel half of train_step: the
+        caller exchanges ``_garena`` and calls :meth:`adam_step`)."""
+        plan = self._run_forward(input_ids, train=True, new_step=True, last_only=True)
+        self._run_loss_bce(plan, answers, neg_answers)
+        self._run_backward(plan)
+        return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
     def train_step(self, input_ids, answers, neg_answers=None) -> torch.Tensor:
         """step_begin + forward + BCE head + backward + fused Adam, all on the device (five C calls)."""
         if self._adam is None:
             raise RuntimeError("call configure_adam() first")
-        plan = self._run_forward(input_ids, train=True, new_step=True, last_only=True)
-        self._run_loss_bce(plan, answers, neg_answers)
-        self._run_backward(plan)
+        loss = self.grad_step(input_ids, answers, neg_answers)
         self.adam_step()
-        return plan.view(L.BUF_LOSS, 0, (1,))[0]
+        return loss
 
 
 class _LogSigFn(_BCEFn):
@@ -728,14 +764,18 @@ class FMLPRecModel(BSARecModel):
         self._run_loss_pair(plan, answers, neg_answers)
         return plan.view(L.BUF_LOSS, 0, (1,))[0].clone()
 
-    def train_step(self, input_ids, answers, neg_answers=None) -> torch.Tensor:
-        if self._adam is None:
-            raise RuntimeError("call configure_adam() first")
+    def grad_step(self, input_ids, answers, neg_answers=None) -> torch.Tensor:
         plan = self._run_forward(input_ids, train=True, new_step=True, last_only=True)
         self._run_loss_pair(plan, answers, neg_answers)
         self._run_backward(plan)
-        self.adam_step()
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
+    def train_step(self, input_ids, answers, neg_answers=None) -> torch.Tensor:
+        if self._adam is None:
+            raise RuntimeError("call configure_adam() first")
+        loss = self.grad_step(input_ids, answers, neg_answers)
+        self.adam_step()
+        return loss
 
 
 class DuoRecModel(SASRecModel):

@@ -214,6 +214,18 @@ class Trainer:
         return [recall[0], ndcg[0], recall[1], ndcg[1], recall[3], ndcg[3]], str(post_fix)
 
     # ---- one optimisation step --------------------------------------------------------------------
+    def _exchange_and_adam(self):
+        """Eager data-parallel tail of a step: the gradient arena is complete on every rank -> ONE exchange -> fused Adam on
+        the mean (identical replicas)."""
+        m = self.model
+        if self.exchange == "p2p":                  # (parity 0 arena; not the indexed fast path)
+            self._px.barrier(torch.cuda.current_stream(self.device).cuda_stream)
+            m.adam_step(grad_scale=1.0 / self.world, grad_srcs=self._px.grad_srcs(0))
+            self._px.barrier(torch.cuda.current_stream(self.device).cuda_stream)       # single arena here: readers done
+        else:
+            scale = allreduce_sum_(m._gbuf if self.exchange == "rccl_bucketed" else m._garena, self.pg, force=True)
+            m.adam_step(grad_scale=scale)
+
     def _step_eager(self, ids, ans):
         m = self.model
         if not self.dp:
@@ -223,15 +235,22 @@ class Trainer:
         plan = m._run_forward(ids, train=True, new_step=True)
         m._run_loss(plan, ans)
         m._run_backward(plan)
-        if self.exchange == "p2p":                  # (parity 0 arena; not the indexed fast path)
-            self._px.barrier(torch.cuda.current_stream(self.device).cuda_stream)
-            m.adam_step(grad_scale=1.0 / self.world, grad_srcs=self._px.grad_srcs(0))
-            self._px.barrier(torch.cuda.current_stream(self.device).cuda_stream)       # single arena here: readers done
-        else:
-            scale = allreduce_sum_(m._gbuf if self.exchange == "rccl_bucketed" else m._garena, self.pg, force=True)
-            m.adam_step(grad_scale=scale)
+        self._exchange_and_adam()
         from . import _lib as L
         return plan.view(L.BUF_LOSS, 0, (1,))[0]
+
+    def _allreduce_param_grads(self):
+        """Sibling models that train through ``torch.optim`` (DuoRec): the mean of the ranks' ``p.grad`` in ONE coalesced
+        all-reduce (what DistributedDataParallel would do; the reference itself is single-device)."""
+        ps = [p for p in self.model.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        flat.mul_(1.0 / self.world)
+        o = 0
+        for p in ps:
+            n = p.grad.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
+            o += n
 
     def _step_graph(self, ids, ans):
         """Replay the whole step from a hipGraph captured per batch size (static id/answer buffers)."""
@@ -475,8 +494,6 @@ class Trainer:
                     # sibling models whose loss combines several forward passes (DuoRec): the reference's own loop --
                     # calculate_loss / zero_grad / backward / Adam.step over model.parameters() (src/trainers.py:103-107);
                     # every forward / backward is the HIP path, the optimiser walks the arena views
-                    if self.dp:
-                        raise NotImplementedError("data parallel is built for the BSARec step only")
                     if getattr(self, "_torch_opt", None) is None:
                         self._torch_opt = torch.optim.Adam(self.model.parameters(), lr=self.args.lr,
                                                            betas=(self.args.adam_beta1, self.args.adam_beta2),
@@ -484,12 +501,16 @@ class Trainer:
                     loss = self.model.calculate_loss(input_ids, answers, neg_answers, same_target, user_ids)
                     self._torch_opt.zero_grad()
                     loss.backward()
+                    if self.dp and self.world > 1:
+                        self._allreduce_param_grads()
                     self._torch_opt.step()
                     loss = loss.detach()
                 elif pairwise:
-                    if self.dp:
-                        raise NotImplementedError("data parallel is built for the BSARec step only")
-                    loss = self.model.train_step(input_ids, answers, neg_answers)
+                    if self.dp:                     # sibling models with a pos / neg head: local gradients, one exchange, Adam
+                        loss = self.model.grad_step(input_ids, answers, neg_answers)
+                        self._exchange_and_adam()
+                    else:
+                        loss = self.model.train_step(input_ids, answers, neg_answers)
                 elif self.use_graph and not self.dp:
                     B = input_ids.shape[0]
                     first = B not in self._graphs

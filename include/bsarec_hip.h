@@ -188,6 +188,11 @@ int bsarec_backward(bsarec_plan_t *plan, void *stream);
  * (DuoRec's contrastive terms, src/model/duorec.py:95-127). */
 int bsarec_backward_seq(bsarec_plan_t *plan, const float *d_out, void *stream);
 
+/* The same with an upstream gradient for EVERY element of forward(all_sequence_output=True)'s list
+ * (src/model/bsarec.py:46-54: index 0 = embedding output, index l = output of block l - 1, index N = the last layer):
+ * d_outs[0..N], fp32 [B, L, d] each; d_outs[N] must be given, d_outs[l < N] may be NULL (no gradient for that output). */
+int bsarec_backward_seq_multi(bsarec_plan_t *plan, const float *const *d_outs, void *stream);
+
 /* torch.optim.Adam (src/trainers.py:27-28,107) over flat arenas: one struct for every entry point that updates. */
 typedef struct {
     float *params;            /* [n] fp32 master parameters (n % 4 == 0) */

@@ -176,3 +176,77 @@ def test_duorec_trains_through_the_driver():
     scores, info, epochs, secs = M.run(args, seqs, logger)
     assert losses[-1] < losses[0] - 0.1, losses           # CE over 3,647 classes starts at ~8.2 + the contrastive terms
     assert scores[2] > 0.01, scores                          # HR@10 above chance (0.0027)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [1, 0])
+def test_all_sequence_output_list_is_one_autograd_graph(fused):
+    """forward(all_sequence_output=True) (src/model/bsarec.py:46-54): every element of the list carries gradients.  With
+    dropout off the gradient of  sum_l <g_l, out_l>  decomposes exactly: out_2 is the 2-layer model's output, out_1 the output
+    of the SAME weights truncated to one layer, out_0 the embedding front-end (plain torch here) -- the single-output backward
+    of each is already pinned by the oracle / reference goldens (bsarec_backward_seq), so the multi-output node must equal
+    their sum.  fused = 1: per-sequence block kernels (the embedding gradient joins inside the bottom block's epilogue);
+    fused = 0: generic tiled kernels."""
+    import argparse
+    from bsarec_amd import BSARecModel, _lib as Lb
+    old = Lb.set_default_options(no_fused=1 - fused)
+    try:
+        def ns(layers):
+            return argparse.Namespace(item_size=151, hidden_size=64, max_seq_length=50, batch_size=8, hidden_dropout_prob=0.0,
+                                      attention_probs_dropout_prob=0.0, num_hidden_layers=layers, num_attention_heads=2,
+                                      hidden_act="gelu", initializer_range=0.02, c=5, alpha=0.7, seed=1)
+        torch.manual_seed(3)
+        m2 = BSARecModel(ns(2)).cuda()
+        with torch.no_grad():
+            for k, p in m2.named_parameters():
+                if k.endswith(".bias"):
+                    p.normal_(0, 0.05)
+        m2.train()
+        m1 = BSARecModel(ns(1)).cuda()
+        sd2 = m2.state_dict()
+        m1.load_state_dict({k: sd2[k] for k in m1.state_dict()})
+        m1.train()
+        rng = np.random.default_rng(0)
+        ids = np.zeros((6, 50), dtype=np.int64)
+        for b in range(6):
+            n = int(rng.integers(1, 51))
+            ids[b, 50 - n:] = rng.integers(1, 151, size=n)
+        ids = torch.from_numpy(ids).cuda()
+        g = [torch.randn(6, 50, 64, device="cuda") for _ in range(3)]
+
+        outs = m2.forward(ids, all_sequence_output=True)
+        assert len(outs) == 3 and all(o.requires_grad for o in outs)
+        (sum((gi * oi).sum() for gi, oi in zip(g, outs))).backward()
+        got = {k: p.grad.clone() for k, p in m2.named_parameters()}
+
+        for p in m2.parameters():
+            p.grad = None
+        (g[2] * m2.forward(ids)).sum().backward()                    # the last layer alone
+        want = {k: p.grad.clone() for k, p in m2.named_parameters()}
+        (g[1] * m1.forward(ids)).sum().backward()                    # block 0's output = the 1-layer model's output
+        for k, p in m1.named_parameters():
+            want[k] += p.grad
+        # embedding output (dropout off): LN(E[ids] + Pos) in torch
+        E = sd2["item_embeddings.weight"].clone().requires_grad_(True)
+        P = sd2["position_embeddings.weight"].clone().requires_grad_(True)
+        gw = sd2["LayerNorm.weight"].clone().requires_grad_(True)
+        gb = sd2["LayerNorm.bias"].clone().requires_grad_(True)
+        x = E[ids] + P[None]
+        mu = x.mean(-1, keepdim=True)
+        xh = (x - mu) / torch.sqrt(((x - mu) ** 2).mean(-1, keepdim=True) + 1e-12)
+        out0 = gw * xh + gb
+        np.testing.assert_allclose(outs[0].detach().cpu().numpy(), out0.detach().cpu().numpy(), atol=2e-5)
+        (g[0] * out0).sum().backward()
+        E.grad[0] = 0                                                # padding_idx = 0: no lookup gradient for the padding row
+        want["item_embeddings.weight"] += E.grad
+        want["position_embeddings.weight"] += P.grad
+        want["LayerNorm.weight"] += gw.grad
+        want["LayerNorm.bias"] += gb.grad
+        for k in got:
+            a, b = got[k].cpu().numpy(), want[k].cpu().numpy()
+            if k.endswith("key.bias"):
+                assert np.abs(a).max() <= 1e-4
+                continue
+            assert rel_l2(a, b) <= 2e-5, (k, rel_l2(a, b))
+    finally:
+        Lb.set_default_options(**old)

@@ -130,3 +130,80 @@ def test_prepare_indexed_builds_every_graph_up_front_p2p(tmp_path):
     r0, r1 = np.load(tmp_path / "prep0.npz"), np.load(tmp_path / "prep1.npz")
     assert int(r0["ran"]) == int(r1["ran"])
     np.testing.assert_array_equal(r0["arena"], r1["arena"])
+
+
+# ---- data parallel for the sibling models (SASRec / FMLPRec: fused step split around the exchange; DuoRec: torch.optim loop
+#      with one coalesced all-reduce of p.grad) ------------------------------------------------------------------------------
+
+def _sib_batches(kind, B, steps, V=301, L=50):
+    rng = np.random.default_rng(17)
+    out = []
+    for _ in range(steps):
+        ids = np.zeros((B, L), dtype=np.int64)
+        for b in range(B):
+            n = int(rng.integers(1, L + 1))
+            ids[b, L - n:] = rng.integers(1, V, size=n)
+        ans = rng.integers(1, V, size=B).astype(np.int64)
+        neg = rng.integers(1, V, size=B).astype(np.int64)
+        same = np.zeros((B, L), dtype=np.int64)
+        for b in range(B):
+            n = int(rng.integers(1, L + 1))
+            same[b, L - n:] = rng.integers(1, V, size=n)
+        out.append((np.arange(B, dtype=np.int64), ids, ans, neg, same))
+    return out
+
+
+def _sib_ns(kind):
+    a = _ns()
+    a.contrast, a.tau, a.lmd, a.lmd_sem, a.ssl, a.sim = "us_x", 1.0, 0.1, 0.1, "us_x", "dot"
+    return a
+
+
+def _sib_worker(rank, world, port, kind, out_dir):
+    import torch.distributed as dist
+    from bsarec_amd import MODEL_DICT
+    from bsarec_amd.trainer import Trainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1)
+        model = MODEL_DICT[kind](args=_sib_ns(kind)).cuda()
+        model.set_seed(5, rank)
+        Bl = 16
+        batches = [tuple(torch.from_numpy(t[rank * Bl:(rank + 1) * Bl]).cuda() for t in bt) for bt in _sib_batches(kind, 2 * Bl, 3)]
+        tr = Trainer(model, batches, None, None, _sib_ns(kind), None, use_graph=False, process_group=dist.group.WORLD, exchange="rccl")
+        losses = [float(tr.train(e)["rec_loss"]) for e in range(2)]
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        np.savez(os.path.join(out_dir, f"sib{rank}.npz"), losses=np.asarray(losses), **sd)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["sasrec", "fmlprec", "duorec"])
+def test_two_ranks_sibling_models(kind, tmp_path):
+    """Trainer(process_group=...) for the sibling models: replicas stay bit-identical; for the pos / neg heads (SASRec,
+    FMLPRec: the loss is a mean over sequences) two ranks equal ONE process on the global batch; DuoRec's in-batch
+    contrastive terms differ between a 2 x 16 and a 32 batch by construction, so there only the replicas are compared."""
+    import torch.multiprocessing as mp
+    from bsarec_amd import MODEL_DICT
+    from bsarec_amd.trainer import Trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_sib_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "sib0.npz"), np.load(tmp_path / "sib1.npz")
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    assert np.isfinite(r0["losses"]).all()
+    if kind == "duorec":
+        return
+    torch.manual_seed(1)
+    model = MODEL_DICT[kind](args=_sib_ns(kind)).cuda()
+    model.set_seed(5)
+    batches = [tuple(torch.from_numpy(t).cuda() for t in bt) for bt in _sib_batches(kind, 32, 3)]
+    tr = Trainer(model, batches, None, None, _sib_ns(kind), None, use_graph=False)
+    losses = [float(tr.train(e)["rec_loss"]) for e in range(2)]
+    np.testing.assert_allclose(r0["losses"], losses, atol=2e-4)
+    sd = model.state_dict()
+    for k in sd:
+        got, want = r0[k], sd[k].detach().cpu().numpy()
+        bad = np.abs(got - want) > 2e-5
+        assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - want).max())
