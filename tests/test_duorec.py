@@ -188,6 +188,7 @@ def test_all_sequence_output_list_is_one_autograd_graph(fused):
     their sum.  fused = 1: per-sequence block kernels (the embedding gradient joins inside the bottom block's epilogue);
     fused = 0: generic tiled kernels."""
     import argparse
+    torch = pytest.importorskip("torch")
     from bsarec_amd import BSARecModel, _lib as Lb
     old = Lb.set_default_options(no_fused=1 - fused)
     try:
