@@ -188,6 +188,39 @@ class ShardedCatalogue:
             L.check(lib.bsarec_adam_apply(C.byref(ae), enc._state.data_ptr(), st), "bsarec_adam_apply")
         return self.loss[0]
 
+    def train_step_graph(self, input_ids, answers) -> torch.Tensor:
+        """:meth:`train_step` replayed from ONE hipGraph: the kernels AND the collectives between them (all-gathers of
+        h_last / answers / ids / statistics, the all-reduce of d h_last -- torch.distributed over RCCL enqueues them on the
+        capture stream, as the data-parallel step's in-graph all-reduce does) are captured once for this rank's static
+        input buffers; every later call copies the batch in and launches the graph: no host work between the step's ~25
+        launches.  The first call runs eagerly (plans, kernel attributes, communicators) and captures; if the backend's
+        collectives cannot be captured (gloo in the tests) the step stays eager -- ``graph_captured`` says which."""
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        ans = answers.to(device=self.device, dtype=torch.int64).contiguous()
+        if getattr(self, "_graph", None) is None and not getattr(self, "_graph_failed", False):
+            self._sid, self._sans = ids.clone(), ans.clone()
+            loss = self.train_step(self._sid, self._sans).clone()
+            torch.cuda.synchronize(self.device)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    gl = self.train_step(self._sid, self._sans)
+                self._graph = (g, gl)
+            except Exception as e:                    # capture of a collective refused: eager from now on
+                self._graph_failed, self._graph_error = True, f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize(self.device)
+            return loss
+        if getattr(self, "_graph", None) is not None:
+            self._sid.copy_(ids)
+            self._sans.copy_(ans)
+            self._graph[0].replay()
+            return self._graph[1]
+        return self.train_step(ids, ans)
+
+    @property
+    def graph_captured(self) -> bool:
+        return getattr(self, "_graph", None) is not None
+
     # ---- evaluation ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def topk(self, input_ids, k: int = 20, seen=None):

@@ -297,3 +297,46 @@ def test_one_shard_of_C5_at_its_own_shape():
     torch.testing.assert_close(dh.double(), dh_want, rtol=1e-4, atol=1e-8)
     print("C5 shard head, ms: logits %.2f  ce_grad %.2f  head_bwd %.2f" %
           (ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3]), ev[3].elapsed_time(ev[4])))
+
+
+def _graph_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from bsarec_amd.catalogue import ShardedCatalogue
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+    try:
+        ns = _ns(hidden_dropout_prob=0.3, attention_probs_dropout_prob=0.2)
+        B = ns.batch_size
+        res = {}
+        for mode in ("eager", "graph"):
+            torch.manual_seed(7)                                     # the encoder replica draws its weights from torch's generator
+            sc = ShardedCatalogue(ns, B, dist.group.WORLD, "cuda:0")
+            losses = []
+            for ids, ans in _batches(ns, 4, B):
+                step = sc.train_step_graph if mode == "graph" else sc.train_step
+                losses.append(float(step(ids.cuda(), ans.cuda()).item()))
+            if mode == "graph":
+                assert sc.graph_captured, getattr(sc, "_graph_error", "no capture attempted")
+            sc.check_exchange()
+            res[mode] = (losses, {k: v.detach().cpu().numpy() for k, v in sc.full_state_dict().items()})
+            sc.close()
+        np.savez(os.path.join(out_dir, "graph.npz"), le=np.asarray(res["eager"][0]), lg=np.asarray(res["graph"][0]),
+                 **{"e/" + k: v for k, v in res["eager"][1].items()}, **{"g/" + k: v for k, v in res["graph"][1].items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_step_replays_from_one_graph_with_its_collectives_rccl_one_rank(tmp_path):
+    """ShardedCatalogue.train_step_graph: the whole catalogue-sharded step -- ~25 kernels and the five collectives between
+    them -- captured in ONE hipGraph over RCCL (a 1-rank group: the only RCCL group a one-GPU box can form; the collectives are
+    real RCCL calls on the capture stream) and replayed: same losses and parameters as the eager step (same dropout stream)."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_graph_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    z = np.load(tmp_path / "graph.npz")
+    np.testing.assert_allclose(z["lg"], z["le"], rtol=1e-5)
+    for k in [k[2:] for k in z.files if k.startswith("e/")]:
+        a, b = z["g/" + k], z["e/" + k]
+        bad = np.abs(a - b) > 2e-5
+        assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(a - b).max())
