@@ -63,7 +63,7 @@ def _env_defaults():
         d["separate_top"] = 1
     if e.get("BSAREC_FUSED") == "0":
         d["no_fused"] = 1
-    if e.get("BSAREC_BLOCK_KERNELS") == "phase":
+    if e.get("BSAREC_BLOCK_KERNELS") == "chain":
         d["chain_kernels"] = 1
     for env, key, hi in (("BSAREC_TOP_SLABS", "top_slabs", 16), ("BSAREC_SPLITS", "splits", 1024)):
         if e.get(env, "").isdigit() and 1 <= int(e[env]) <= hi:

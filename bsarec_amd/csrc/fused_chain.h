@@ -235,17 +235,19 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         }
     };
     issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{}); issue(std::integral_constant<int, 2>{});
+    float vec0, vec1;
     {   // the small per-feature vectors go through LDS once: read where they are needed, a global load would expose an L2 round
         // trip on the single chain of a wave (the stamps of the first pair build: 2-3 k cycles per LayerNorm stage)
         const float* v0 = wave == 0 ? KARG(FusedFwdP, bq) : wave == 1 ? KARG(FusedFwdP, bk) : wave == 2 ? KARG(FusedFwdP, bv) : wave == 3 ? KARG(FusedFwdP, bo) :
                           wave == 4 ? KARG(FusedFwdP, b2) : wave == 5 ? KARG(FusedFwdP, f_g) : wave == 6 ? KARG(FusedFwdP, f_b) : KARG(FusedFwdP, a_g);
         const float* v1 = wave == 0 ? KARG(FusedFwdP, a_b) : wave == 1 ? KARG(FusedFwdP, ff_g) : wave == 2 ? KARG(FusedFwdP, ff_b) : wave == 3 ? KARG(FusedFwdP, sqrt_beta) :
                           KARG(FusedFwdP, b1) + 64 * (wave - 4);
-        sVec[64 * wave + lane] = gld(v0 + lane);
-        sVec[512 + 64 * wave + lane] = gld(v1 + lane);
+        vec0 = gld(v0 + lane); vec1 = gld(v1 + lane);               // (stored to LDS after phase 0: their round trip hides behind it)
     }
     __builtin_amdgcn_sched_barrier(0);
     chain_phase0(sX, sIds, sTab, dseed, L, cb, tok0, b);
+    sVec[64 * wave + lane] = vec0;
+    sVec[512 + 64 * wave + lane] = vec1;
     fill(std::integral_constant<int, 0>{});
     issue(std::integral_constant<int, 3>{});
     STAMP(1);
@@ -350,6 +352,12 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             f32x4 a0 = bia[u][0], a1 = bia[u][1];
+            // (running the upper wave's FrequencyLayer slice BEFORE its MFMAs -- a stagger of the two waves of a SIMD -- was
+            //  measured: 20.0 k -> 21.5 k cycles for this stage, not kept)
+            auto slice = [&]() {
+                if (!tile_on) return;
+                if (u == 0) spectrum(); else dsp_rows(2 * half + (u - 1));
+            };
             if (tile_on) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -374,18 +382,16 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
                         for (int r = 0; r < 4; ++r) { c0 = mfma16(wq2[c][r], x[c][r], c0); c1 = mfma16(wq2[4 + c][r], x[c][r], c1); }
                     q[NQ == 4 ? 2 - o0 : 0] = c0; q[NQ == 4 ? 3 - o0 : 1] = c1;
                 }
-                if (tile_on) spectrum();
             } else if (u == 1) {
                 st4(sK + t * FS + 16 * o0 + 4 * g, a0); st4(sK + t * FS + 16 * (o0 + 1) + 4 * g, a1);
-                if (tile_on) dsp_rows(2 * half);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     sVt[(16 * o0 + 4 * g + r) * FS + t] = a0[r];
                     sVt[(16 * (o0 + 1) + 4 * g + r) * FS + t] = a1[r];
                 }
-                if (tile_on) dsp_rows(2 * half + 1);
             }
+            slice();
             if (u == 0) UNIT_BEGIN(1, 8 * half, 8 * half + 4)
             if (u == 1) UNIT_BEGIN(2, 8 * half, 8 * half + 4)
         }
@@ -581,6 +587,10 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         }
     }
     STAMP(6);
+    // TAIL: the top block's weight fragments are requested here, in the shadow of the hand-over and the final row pass (lane n
+    // reads ITS weight row: ~50 address-path cycles per wave instruction, the wave cannot move on before they are issued)
+    TopFwdRegs<false> TR;
+    if constexpr (TAIL) { if (half == 0) top_fwd_prefetch<false, KOFF>(TR); }
     if (half == 1) {
         if (tile_on) {
 #pragma unroll
@@ -616,8 +626,6 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     STAMP(7);
     if constexpr (TAIL) {
         // the one-row top block as this kernel's tail (fused_top.h): its x tile = this block's output, rows >= L zero
-        TopFwdRegs<false> TR;
-        top_fwd_prefetch<false, KOFF>(TR);
 #pragma unroll
         for (int o = 0; o < 4; ++o) st4(sX + t * FS + 16 * o + 4 * g, y[o]);
         lds_barrier();                                               // ---- (waves 0..3 only: waves 4..7 have exited)
