@@ -14,8 +14,10 @@
  *     driven from different threads;
  *   - return value: 0 = OK, < 0 = invalid argument / unsupported shape (nothing was launched),
  *     > 0 = hipError_t of a failed launch;
- *   - fp32 everywhere (the reference's arithmetic type); ids and answers are int64 as produced by
- *     the reference DataLoader (src/dataset.py:108-115).
+ *   - fp32 arithmetic and fp32 tensors by default (the reference's arithmetic type); cfg.storage = 1 keeps the
+ *     saved activations / inter-block gradients / a shadow of the Linear weights in bf16 and multiplies with
+ *     bf16 MFMAs (fp32 accumulation, fp32 masters, LayerNorm / softmax / loss / Adam in fp32) at the fused
+ *     shape; ids and answers are int64 as produced by the reference DataLoader (src/dataset.py:108-115).
  */
 #ifndef BSAREC_HIP_H
 #define BSAREC_HIP_H
