@@ -618,6 +618,14 @@ def main():
             sec["C2_storage_bf16"] = secondary_bf16(a, dev, users, inputs, answers, D, BSARecModel, Trainer)
         except Exception as e:
             sec["C2_storage_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            sec["C2_beauty_bf16"] = secondary_beauty_bf16(dev, D, BSARecModel, Trainer)
+        except Exception as e:
+            sec["C2_beauty_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            sec["C4_per_rank_shape"] = secondary_c4(dev, D, BSARecModel, Trainer)
+        except Exception as e:
+            sec["C4_per_rank_shape"] = {"error": f"{type(e).__name__}: {e}"}
         out["secondary"] = sec
     if solo and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
@@ -650,6 +658,63 @@ def secondary_bf16(a, dev, users, inputs, answers, D, BSARecModel, Trainer, step
             "dtype": "bf16", "value": round(a.batch * steps / dt, 1), "unit": "sequences/s", "ms_per_step": round(1e3 * dt / steps, 4),
             "steps": steps, "parity_gates": "tests/test_gpu_bf16.py: logits <= 5e-3 rel-Linf, loss <= 5e-4 rel, grads <= 2e-2 rel-L2 vs the fp32 oracle; "
                                             "KAT-1 Beauty metrics equal to 4 decimals"}
+
+
+def secondary_beauty_bf16(dev, D, BSARecModel, Trainer, steps=100, warmup=10):
+    """BASELINE config 2 at ITS OWN shape: Amazon-Beauty (the real interaction sequences, carried by the committed fixture
+    tests/golden/kat_Beauty.npz -- the reference mount does not exist on the GPU box), V = 12,102, L = 50, d = 64, 2 layers,
+    1 head, c = 5, alpha = 0.7, lr 5e-4 (reference README.md:43-48), B = 256, bf16 storage."""
+    import numpy as np
+    import torch
+    path = os.path.join(ROOT, "tests", "golden", "kat_Beauty.npz")
+    z = np.load(path)
+    cfg = json.loads(str(z["cfg"]))
+    off, items = z["seq_offsets"], z["seq_items"]
+    seqs = [items[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+    a2 = argparse.Namespace(item_size=cfg["item_size"], hidden=64, seq_len=50, batch=256, layers=2, heads=cfg["num_attention_heads"], dtype="bf16")
+    m2 = model_args(a2)
+    m2.c, m2.alpha, m2.lr = cfg["c"], cfg["alpha"], 5e-4
+    torch.manual_seed(42)
+    model = BSARecModel(m2).to(dev)
+    model.set_seed(42, 0)
+    model.train()
+    u, x, y = D.train_table(seqs, 50)
+    bt = D.DeviceBatches(u, x, y, 256, dev, shuffle=True, seed=42)
+    tr = Trainer(model, bt, None, None, m2, None, use_graph=True)
+    dt, loss = timed_steps(Feed(tr, bt, dev), steps, warmup, torch.cuda.synchronize)
+    assert np.isfinite(float(loss.item()))
+    fl = train_flops_per_seq(a2, cb=cfg["c"] // 2 + 1)
+    return {"workload": f"C2: Amazon-Beauty (real sequences, {len(y)} training samples, {float((x == 0).mean()):.2f} padding), V={cfg['item_size']} "
+                        f"L=50 d=64 2 layers 1 head c={cfg['c']} alpha={cfg['alpha']}, B=256, bf16 storage",
+            "dtype": "bf16", "value": round(256 * steps / dt, 1), "unit": "sequences/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+            "step_bf16_mfma_frac": round(fl * 256 * steps / dt / (BF16_MFMA_PEAK_TFLOPS * 1e12), 5),
+            "parity": "tests/test_gpu_config_shapes.py::test_c2_beauty_shape_bf16_training_step_vs_fp32_oracle"}
+
+
+def secondary_c4(dev, D, BSARecModel, Trainer, steps=40, warmup=5):
+    """BASELINE config 4's PER-RANK step (Yelp shape: V = 20,034, L = 50, d = 64, 2 layers, 2 heads; global batch 8,192 over
+    8 ranks = 1,024 sequences per rank), fp32, on one GPU -- the 8-way shard itself needs a node; synthetic Yelp-shaped data
+    (the real file is not on the GPU box)."""
+    import numpy as np
+    import torch
+    a4 = argparse.Namespace(item_size=20034, hidden=64, seq_len=50, batch=1024, layers=2, heads=2, dtype="f32")
+    m4 = model_args(a4)
+    torch.manual_seed(42)
+    model = BSARecModel(m4).to(dev)
+    model.set_seed(42, 0)
+    model.train()
+    seqs = D.synth_ml1m_like(seed=7, n_users=3000, n_items=20033)
+    u, x, y = D.train_table(seqs, 50)
+    bt = D.DeviceBatches(u, x, y, 1024, dev, shuffle=True, seed=42)
+    tr = Trainer(model, bt, None, None, m4, None, use_graph=True)
+    tr.steps_per_graph = 4
+    dt, loss = timed_steps(Feed(tr, bt, dev), steps, warmup, torch.cuda.synchronize)
+    assert np.isfinite(float(loss.item()))
+    fl = train_flops_per_seq(a4, cb=2)
+    return {"workload": "C4 per-rank step: Yelp shape V=20034 L=50 d=64 2 layers 2 heads, B=1024 on ONE GPU (1/8 of the global batch 8192), fp32",
+            "value": round(1024 * steps / dt, 1), "unit": "sequences/s", "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+            "step_mfma_frac": round(fl * 1024 * steps / dt / (FP32_MFMA_PEAK_TFLOPS * 1e12), 5),
+            "parity": "tests/test_gpu_config_shapes.py (oracle parity at V=20034; 2 ranks x 1024 == one process x 2048)"}
 
 
 def secondary_c3(dev, seqs, D, BSARecModel, Trainer, steps=15, warmup=3):

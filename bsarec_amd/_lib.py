@@ -5,7 +5,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSAREC_LIB") or os.path.join(HERE, "libbsarec_hip.so")   # BSAREC_LIB: another build of the same ABI
 MAX_LAYERS = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 (BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX,
  BUF_DLOGITS) = range(10)
@@ -39,10 +39,10 @@ class Config(C.Structure):
                 # per-plan options, 0 = default (include/bsarec_hip.h)
                 ("hidden_act", C.c_int), ("storage", C.c_int), ("no_fused", C.c_int), ("no_prune_top", C.c_int),
                 ("dw_tiled", C.c_int), ("splits", C.c_int), ("top_slabs", C.c_int), ("separate_embed", C.c_int),
-                ("separate_top", C.c_int), ("chain_kernels", C.c_int)]
+                ("separate_top", C.c_int), ("chain_kernels", C.c_int), ("x3_products", C.c_int)]
 
 
-OPTION_FIELDS = ("storage", "no_fused", "no_prune_top", "dw_tiled", "splits", "top_slabs", "separate_embed", "separate_top", "chain_kernels")
+OPTION_FIELDS = ("storage", "no_fused", "no_prune_top", "dw_tiled", "splits", "top_slabs", "separate_embed", "separate_top", "chain_kernels", "x3_products")
 HIDDEN_ACTS = {"gelu": 0, "relu": 1, "swish": 2, "tanh": 3, "sigmoid": 4}      # src/model/_modules.py:38-45
 
 # Plan options the HOST gives to plans it creates from now on.  The C ABI has no process-wide state: these are Python
@@ -65,6 +65,8 @@ def _env_defaults():
         d["no_fused"] = 1
     if e.get("BSAREC_BLOCK_KERNELS") == "chain":
         d["chain_kernels"] = 1
+    if e.get("BSAREC_PRODUCTS") == "bf16x3":
+        d["x3_products"] = 1
     for env, key, hi in (("BSAREC_TOP_SLABS", "top_slabs", 16), ("BSAREC_SPLITS", "splits", 1024)):
         if e.get(env, "").isdigit() and 1 <= int(e[env]) <= hi:
             d[key] = int(e[env])

@@ -584,7 +584,7 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
     TopFwdP TF;
     if (top_tail) fill_top_fwd(p, l + 1, tr, TF);
-    if (!p.bf && c.chain_kernels) {
+    if (!p.bf && c.chain_kernels && !c.x3_products) {
         // register-chain forward (fused_chain.h): one wave per 16-token tile, two workgroup barriers
         const size_t csm = fused_chain_fwd_smem_bytes(top_tail);
 #define CHAIN_FWD_CASE(DHV) { \
@@ -601,17 +601,18 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
         return (int)hipGetLastError();
     }
     const size_t smem = fused_fwd_smem_bytes();
-#define FUSED_FWD_CASE(DHV, BFV) { \
+#define FUSED_FWD_CASE(DHV, BFV, X3V) { \
         static bool attr = false, attr_t = false; \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV, NoTail>), \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV, NoTail, X3V>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
-        if (!attr_t) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV, TopFwdP>), \
+        if (!attr_t) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<DHV, BFV, TopFwdP, X3V>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_t = true; } \
         ProfScope prof(BSAREC_K_FUSED_FWD, s); \
-        if (top_tail) LAUNCH((fused_layer_fwd_kernel<DHV, BFV, TopFwdP>), dim3(c.batch), dim3(512), smem, s, F, TF); \
-        else LAUNCH((fused_layer_fwd_kernel<DHV, BFV, NoTail>), dim3(c.batch), dim3(512), smem, s, F, NoTail()); }
-    if (p.bf) { if (p.dh == 16) FUSED_FWD_CASE(16, true) else if (p.dh == 32) FUSED_FWD_CASE(32, true) else FUSED_FWD_CASE(64, true) }
-    else { if (p.dh == 16) FUSED_FWD_CASE(16, false) else if (p.dh == 32) FUSED_FWD_CASE(32, false) else FUSED_FWD_CASE(64, false) }
+        if (top_tail) LAUNCH((fused_layer_fwd_kernel<DHV, BFV, TopFwdP, X3V>), dim3(c.batch), dim3(512), smem, s, F, TF); \
+        else LAUNCH((fused_layer_fwd_kernel<DHV, BFV, NoTail, X3V>), dim3(c.batch), dim3(512), smem, s, F, NoTail()); }
+    if (p.bf) { if (p.dh == 16) FUSED_FWD_CASE(16, true, false) else if (p.dh == 32) FUSED_FWD_CASE(32, true, false) else FUSED_FWD_CASE(64, true, false) }
+    else if (c.x3_products) { if (p.dh == 16) FUSED_FWD_CASE(16, false, true) else if (p.dh == 32) FUSED_FWD_CASE(32, false, true) else FUSED_FWD_CASE(64, false, true) }
+    else { if (p.dh == 16) FUSED_FWD_CASE(16, false, false) else if (p.dh == 32) FUSED_FWD_CASE(32, false, false) else FUSED_FWD_CASE(64, false, false) }
 #undef FUSED_FWD_CASE
     return (int)hipGetLastError();
 }
@@ -647,17 +648,18 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.trash = p.trash;
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = fused_bwd_smem_bytes();
-#define FUSED_BWD_CASE(DHV, BFV) { \
+#define FUSED_BWD_CASE(DHV, BFV, X3V) { \
         static bool attr = false; \
-        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV, NoTail>), \
+        if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV, NoTail, X3V>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-                     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV, TopBwdP>), \
+                     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV, TopBwdP, X3V>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr = true; } \
         ProfScope prof(BSAREC_K_FUSED_BWD, s); \
-        if (head) LAUNCH((fused_layer_bwd_kernel<DHV, BFV, TopBwdP>), dim3(c.batch), dim3(512), smem, s, F, *head); \
-        else LAUNCH((fused_layer_bwd_kernel<DHV, BFV, NoTail>), dim3(c.batch), dim3(512), smem, s, F, NoTail()); }
-    if (p.bf) { if (p.dh == 16) FUSED_BWD_CASE(16, true) else if (p.dh == 32) FUSED_BWD_CASE(32, true) else FUSED_BWD_CASE(64, true) }
-    else { if (p.dh == 16) FUSED_BWD_CASE(16, false) else if (p.dh == 32) FUSED_BWD_CASE(32, false) else FUSED_BWD_CASE(64, false) }
+        if (head) LAUNCH((fused_layer_bwd_kernel<DHV, BFV, TopBwdP, X3V>), dim3(c.batch), dim3(512), smem, s, F, *head); \
+        else LAUNCH((fused_layer_bwd_kernel<DHV, BFV, NoTail, X3V>), dim3(c.batch), dim3(512), smem, s, F, NoTail()); }
+    if (p.bf) { if (p.dh == 16) FUSED_BWD_CASE(16, true, false) else if (p.dh == 32) FUSED_BWD_CASE(32, true, false) else FUSED_BWD_CASE(64, true, false) }
+    else if (c.x3_products) { if (p.dh == 16) FUSED_BWD_CASE(16, false, true) else if (p.dh == 32) FUSED_BWD_CASE(32, false, true) else FUSED_BWD_CASE(64, false, true) }
+    else { if (p.dh == 16) FUSED_BWD_CASE(16, false, false) else if (p.dh == 32) FUSED_BWD_CASE(32, false, false) else FUSED_BWD_CASE(64, false, false) }
 #undef FUSED_BWD_CASE
     return (int)hipGetLastError();
 }

@@ -195,21 +195,58 @@ __device__ __forceinline__ f32x4 lowpass_tab(const float* __restrict__ spec, int
 }
 
 // Weight fragments of a K-deep chunk (K = 64 or 32) in MFMA B-operand registers: issue the loads of the whole chunk,
-// use them later (latency hidden by the caller).  The k values a lane holds follow its A fragment:
-//   fp32 (v_mfma_f32_32x32x2_f32): per 8-deep k-block kb, lane half h holds k = 8 kb + 4 h + {0..3}  (one 16-byte load)
-//   bf16 (v_mfma_f32_32x32x16_bf16): per 16-deep k-block s, lane half h holds k = 16 s + 8 h + {0..7}   (one 16-byte load)
-// so the per-lane element offsets carry KH = 4 h (fp32) resp. 8 h (bf16), for the LDS rows and the weight rows alike.
-template <bool BF, int K> struct WFrag;
-template <int K> struct WFrag<false, K> { f32x4 w[K / 8]; };
-template <int K> struct WFrag<true, K> { u32x4 w[K / 16]; };
+// use them later (latency hidden by the caller).  Product mode MM:
+//   0  fp32 MFMA (v_mfma_f32_32x32x2_f32): per 8-deep k-block kb, lane half h holds k = 8 kb + 4 h + {0..3}  (one 16-byte load)
+//   1  bf16 MFMA (v_mfma_f32_32x32x16_bf16) on a bf16 shadow of the weights: per 16-deep k-block s, lane half h holds
+//      k = 16 s + 8 h + {0..7}   (one 16-byte load of the shadow)
+//   2  "x3": fp32 operands, the SAME k layout as mode 1 (two 16-byte loads per k-block), every fp32 product evaluated on
+//      the bf16 matrix cores as six bf16 x bf16 partial products -- see mfma_x3 below.
+// The per-lane element offsets carry KH = 4 h (mode 0) resp. 8 h (modes 1, 2), for the LDS rows and the weight rows alike.
+template <int MM, int K> struct WFrag;
+template <int K> struct WFrag<0, K> { f32x4 w[K / 8]; };
+template <int K> struct WFrag<1, K> { u32x4 w[K / 16]; };
+template <int K> struct WFrag<2, K> { f32x4 w[K / 8]; };            // w[2 s], w[2 s + 1] = the 8 consecutive k of k-block s
+
+// fp32 products on the bf16 matrix cores.  On gfx950 v_mfma_f32_*_f32 executes on the SIMD's vector ALU (no vector
+// instruction of either resident wave issues meanwhile) at 1/16 of the bf16 MFMA rate; the bf16 matrix pipe is
+// separate silicon.  An fp32 value is EXACTLY the sum of three bf16 pieces (a = a1 + a2 + a3, each the round-to-nearest
+// bf16 of the remainder: 3 x 8 significant bits), so a . b = sum over the nine piece products; the six with i + j <= 4
+// carry everything down to 2^-27 |a||b| -- below the fp32 rounding of the accumulation itself (measured on 64 x 256 x 64
+// products against fp64: max error 3.5e-7 of the largest entry, plain fp32 matmul 6.1e-7) -- and each bf16 x bf16
+// product is exact in the MFMA's fp32 accumulator.  Cost per 16-deep k-block of a 32 x 32 tile: 2 x 44 vector instructions
+// (the two splits) + 6 MFMAs on the matrix pipe, against 8 fp32 MFMAs = 520 cycles of the vector ALU.
+struct Split3 { u32x4 h, m, l; };
+__device__ __forceinline__ f32x4 bf_lo4(const u32x4& p, int half) {     // pieces 0..3 (half = 0) or 4..7 (half = 1) widened back
+    return half == 0 ? f32x4{bf_lo(p.x), bf_hi(p.x), bf_lo(p.y), bf_hi(p.y)} : f32x4{bf_lo(p.z), bf_hi(p.z), bf_lo(p.w), bf_hi(p.w)};
+}
+__device__ __forceinline__ Split3 split3(f32x4 a0, f32x4 a1) {
+    Split3 r;
+    r.h = pk8(a0, a1);
+    a0 = a0 - bf_lo4(r.h, 0); a1 = a1 - bf_lo4(r.h, 1);                 // exact: the remainder of a round-to-nearest cut
+    r.m = pk8(a0, a1);
+    a0 = a0 - bf_lo4(r.m, 0); a1 = a1 - bf_lo4(r.m, 1);
+    r.l = pk8(a0, a1);
+    return r;
+}
+__device__ __forceinline__ f32x16 mfma_x3(const Split3& a, const Split3& b, f32x16 acc) {
+    acc = mfma_bf16(a.l, b.h, acc);                                     // smallest terms first
+    acc = mfma_bf16(a.h, b.l, acc);
+    acc = mfma_bf16(a.m, b.m, acc);
+    acc = mfma_bf16(a.m, b.h, acc);
+    acc = mfma_bf16(a.h, b.m, acc);
+    return mfma_bf16(a.h, b.h, acc);
+}
 
 // "rows x weights": B[k][n] = W[n][k], lane n reads its own weight row (contiguous in k); e = element offset of
-// W[n][k0 + KH] in the fp32 master (BF = false) resp. the bf16 shadow (BF = true) behind `base`
-template <bool BF, int K>
-__device__ __forceinline__ void load_w(const float* __restrict__ base, long e, WFrag<BF, K>& f) {
-    if constexpr (BF) {
+// W[n][k0 + KH] in the fp32 master (MM = 0, 2) resp. the bf16 shadow (MM = 1) behind `base`
+template <int MM, int K>
+__device__ __forceinline__ void load_w(const float* __restrict__ base, long e, WFrag<MM, K>& f) {
+    if constexpr (MM == 1) {
 #pragma unroll
         for (int s = 0; s < K / 16; ++s) f.w[s] = *reinterpret_cast<const AS_GLOBAL u32x4*>((const AS_GLOBAL char*)base + 2 * (e + 16 * s));
+    } else if constexpr (MM == 2) {
+#pragma unroll
+        for (int s = 0; s < K / 16; ++s) { f.w[2 * s] = gld4(base + e + 16 * s); f.w[2 * s + 1] = gld4(base + e + 16 * s + 4); }
     } else {
 #pragma unroll
         for (int kb = 0; kb < K / 8; ++kb) f.w[kb] = gld4(base + e + 8 * kb);
@@ -217,9 +254,9 @@ __device__ __forceinline__ void load_w(const float* __restrict__ base, long e, W
 }
 // "x . W": B[k][j] = W[k][j], lane j reads a weight column (stride LDW elements): coalesced dword (fp32) or
 // halfword (bf16) loads; e = element offset of W[k0 + KH][j]
-template <bool BF, int K, int LDW>
-__device__ __forceinline__ void load_wT(const float* __restrict__ base, long e, WFrag<BF, K>& f) {
-    if constexpr (BF) {
+template <int MM, int K, int LDW>
+__device__ __forceinline__ void load_wT(const float* __restrict__ base, long e, WFrag<MM, K>& f) {
+    if constexpr (MM == 1) {
         const AS_GLOBAL unsigned short* g = reinterpret_cast<const AS_GLOBAL unsigned short*>((const AS_GLOBAL char*)base + 2 * e);
 #pragma unroll
         for (int s = 0; s < K / 16; ++s) {
@@ -227,6 +264,13 @@ __device__ __forceinline__ void load_wT(const float* __restrict__ base, long e, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) h[j] = g[(16 * s + j) * LDW];
             f.w[s] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        }
+    } else if constexpr (MM == 2) {
+        const float* gw = base + e;
+#pragma unroll
+        for (int s = 0; s < K / 16; ++s) {
+            f.w[2 * s] = f32x4{gld(gw + (16 * s + 0) * LDW), gld(gw + (16 * s + 1) * LDW), gld(gw + (16 * s + 2) * LDW), gld(gw + (16 * s + 3) * LDW)};
+            f.w[2 * s + 1] = f32x4{gld(gw + (16 * s + 4) * LDW), gld(gw + (16 * s + 5) * LDW), gld(gw + (16 * s + 6) * LDW), gld(gw + (16 * s + 7) * LDW)};
         }
     } else {
         const float* gw = base + e;
@@ -237,12 +281,16 @@ __device__ __forceinline__ void load_wT(const float* __restrict__ base, long e, 
         }
     }
 }
-// acc += rows(sa) . frag: sa = LDS row of this lane + k0 + KH (fp32 tile; converted to bf16 on the way for BF)
-template <bool BF, int K>
-__device__ __forceinline__ void mma_w(const float* __restrict__ sa, const WFrag<BF, K>& f, f32x16& acc) {
-    if constexpr (BF) {
+// acc += rows(sa) . frag: sa = LDS row of this lane + k0 + KH (fp32 tile; converted to bf16 on the way for MM = 1, split for MM = 2)
+template <int MM, int K>
+__device__ __forceinline__ void mma_w(const float* __restrict__ sa, const WFrag<MM, K>& f, f32x16& acc) {
+    if constexpr (MM == 1) {
 #pragma unroll
         for (int s = 0; s < K / 16; ++s) acc = mfma_bf16(pk8(ld4(sa + 16 * s), ld4(sa + 16 * s + 4)), f.w[s], acc);
+    } else if constexpr (MM == 2) {
+#pragma unroll
+        for (int s = 0; s < K / 16; ++s)
+            acc = mfma_x3(split3(ld4(sa + 16 * s), ld4(sa + 16 * s + 4)), split3(f.w[2 * s], f.w[2 * s + 1]), acc);
     } else {
 #pragma unroll
         for (int kb = 0; kb < K / 8; ++kb) {
@@ -253,12 +301,16 @@ __device__ __forceinline__ void mma_w(const float* __restrict__ sa, const WFrag<
     }
 }
 // both operands from LDS rows (k contiguous in each; pointers carry KH): acc += rows(sa) . rows(sb)^T over K
-template <bool BF, int K>
+template <int MM, int K>
 __device__ __forceinline__ void mma_ll(const float* __restrict__ sa, const float* __restrict__ sb, f32x16& acc) {
-    if constexpr (BF) {
+    if constexpr (MM == 1) {
 #pragma unroll
         for (int s = 0; s < K / 16; ++s)
             acc = mfma_bf16(pk8(ld4(sa + 16 * s), ld4(sa + 16 * s + 4)), pk8(ld4(sb + 16 * s), ld4(sb + 16 * s + 4)), acc);
+    } else if constexpr (MM == 2) {
+#pragma unroll
+        for (int s = 0; s < K / 16; ++s)
+            acc = mfma_x3(split3(ld4(sa + 16 * s), ld4(sa + 16 * s + 4)), split3(ld4(sb + 16 * s), ld4(sb + 16 * s + 4)), acc);
     } else {
 #pragma unroll
         for (int kb = 0; kb < K / 8; ++kb) {
@@ -339,10 +391,12 @@ __device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, f
 // TAILP = TopFwdP: the block above is the one-row top block of the loss path and runs as this kernel's tail -- the
 // output tile, the ids and the twiddle table stay in LDS, waves 4..7 exit, waves 0..3 carry on (one launch and the
 // top block's whole load phase saved).
-template <int DH, bool BF, class TAILP>
+template <int DH, bool BF, class TAILP, bool X3 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
 #define PTYPE FusedFwdP
+    static_assert(!(BF && X3), "x3 products work on fp32 tensors");
+    constexpr int MM = X3 ? 2 : (BF ? 1 : 0);       // product mode of the MFMA helpers (WFrag)
     constexpr bool TAIL = IsTail<TAILP>::value;
     constexpr unsigned KOFF = (unsigned)((sizeof(FusedFwdP) + 7) & ~(size_t)7);     // kernarg offset of T_unused
     const auto R0_L = KARG(FusedFwdP, L);
@@ -373,7 +427,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;              // this lane's output feature inside a 64-wide block
-    constexpr int KHM = BF ? 8 : 4;             // k values per lane half and k-block (see WFrag)
+    constexpr int KHM = MM ? 8 : 4;             // k values per lane half and k-block (see WFrag)
     const int KH = KHM * half;
     const long wrow = (long)col * 64 + KH;
     const int arow = (wm * 32 + l31) * FS + KH;
@@ -387,10 +441,10 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     const auto R1_wq = KARG(FusedFwdP, wq);
     // every global LOAD of a phase is issued before the phase's first global STORE: vmcnt retires in issue
     // order, so a load queued behind stores would wait for their write acknowledgements
-    WFrag<BF, 64> wA, wB;
+    WFrag<MM, 64> wA, wB;
     float qkv_bias[3] = {0.f, 0.f, 0.f};
     if (grp == 1) {
-        load_w<BF, 64>(R1_wq, wrow, wA);
+        load_w<MM, 64>(R1_wq, wrow, wA);
         qkv_bias[0] = gld(KARG(FusedFwdP, bq) + col); qkv_bias[1] = gld(KARG(FusedFwdP, bk) + col);
         qkv_bias[2] = gld(KARG(FusedFwdP, bv) + col);
     }
@@ -483,9 +537,9 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            if (which == 0) { load_w<BF, 64>(R2_wk, wrow, wB); mma_w<BF, 64>(sX + arow, wA, acc); }
-            else if (which == 1) { load_w<BF, 64>(R2_wv, wrow, wA); mma_w<BF, 64>(sX + arow, wB, acc); }
-            else mma_w<BF, 64>(sX + arow, wA, acc);
+            if (which == 0) { load_w<MM, 64>(R2_wk, wrow, wB); mma_w<MM, 64>(sX + arow, wA, acc); }
+            else if (which == 1) { load_w<MM, 64>(R2_wv, wrow, wA); mma_w<MM, 64>(sX + arow, wB, acc); }
+            else mma_w<MM, 64>(sX + arow, wA, acc);
             const float bias = qkv_bias[which];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -573,8 +627,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         }
     }
     // dense weights for phase 4 (this group's K half), held across the attention
-    WFrag<BF, 32> wO;
-    load_w<BF, 32>(R2_wo, wrow + 32 * grp, wO);
+    WFrag<MM, 32> wO;
+    load_w<MM, 32>(R2_wo, wrow + 32 * grp, wO);
     lds_barrier();
     // q, k, v -> global as whole rows, 16 B per lane (per-lane dword stores are store-issue bound)
     {
@@ -612,7 +666,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             float mx = -INFINITY;
             if (act) {
-                mma_ll<BF, DH>(sK + (32 * kt + l31) * FS + head * DH + KH, sQ + query * FS + head * DH + KH, st);
+                mma_ll<MM, DH>(sK + (32 * kt + l31) * FS + head * DH + KH, sQ + query * FS + head * DH + KH, st);
                 // scale, mask (-10000, additive, fp32)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -667,16 +721,21 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
                     for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
                     const bool crow_ok = 32 * ct + l31 < DH;
                     const float* va = sVt + (head * DH + 32 * ct + (crow_ok ? l31 : 0)) * FS + 32 * kt + 4 * half;
-                    if constexpr (BF) {
+                    if constexpr (MM != 0) {
                         // the P^T accumulator tile is the B operand as it stands: registers 8s .. 8s+7 of a lane half are
                         // keys 16 s + 8 (j >> 2) + 4 h + (j & 3), so the V^T fragment takes the same two groups of 4 keys
 #pragma unroll
                         for (int s2 = 0; s2 < 2; ++s2) {
                             f32x4 a0 = ld4(va + 16 * s2), a1 = ld4(va + 16 * s2 + 8);
                             if (!crow_ok) { a0 = f32x4{0, 0, 0, 0}; a1 = a0; }
-                            const u32x4 pb = {pk_bf16(st[8 * s2], st[8 * s2 + 1]), pk_bf16(st[8 * s2 + 2], st[8 * s2 + 3]),
-                                              pk_bf16(st[8 * s2 + 4], st[8 * s2 + 5]), pk_bf16(st[8 * s2 + 6], st[8 * s2 + 7])};
-                            cacc = mfma_bf16(pk8(a0, a1), pb, cacc);
+                            if constexpr (MM == 1) {
+                                const u32x4 pb = {pk_bf16(st[8 * s2], st[8 * s2 + 1]), pk_bf16(st[8 * s2 + 2], st[8 * s2 + 3]),
+                                                  pk_bf16(st[8 * s2 + 4], st[8 * s2 + 5]), pk_bf16(st[8 * s2 + 6], st[8 * s2 + 7])};
+                                cacc = mfma_bf16(pk8(a0, a1), pb, cacc);
+                            } else {
+                                cacc = mfma_x3(split3(a0, a1), split3(f32x4{st[8 * s2], st[8 * s2 + 1], st[8 * s2 + 2], st[8 * s2 + 3]},
+                                                                      f32x4{st[8 * s2 + 4], st[8 * s2 + 5], st[8 * s2 + 6], st[8 * s2 + 7]}), cacc);
+                            }
                         }
                     } else {
 #pragma unroll
@@ -728,12 +787,12 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     float ffn_bias[2];
     // ---- phase 4: dense (K split across the groups) + dropout + residual + LayerNorm + alpha mix
     {
-        load_w<BF, 64>(R4_w1, (long)(128 * grp + col) * 64 + KH, wA);      // first dense_1 block of this group
+        load_w<MM, 64>(R4_w1, (long)(128 * grp + col) * 64 + KH, wA);      // first dense_1 block of this group
         ffn_bias[0] = gld(KARG(FusedFwdP, b1) + 128 * grp + col); ffn_bias[1] = gld(KARG(FusedFwdP, b1) + 128 * grp + 64 + col);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w<BF, 32>(sC + arow + 32 * grp, wO, acc);
+        mma_w<MM, 32>(sC + arow + 32 * grp, wO, acc);
         float* part = grp == 0 ? sQ : sK;                                  // sQ / sK are dead: partial tiles
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
@@ -754,14 +813,14 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c256 = (2 * grp + i) * 64 + col;
-            WFrag<BF, 64>& wcur = i ? wB : wA;
-            WFrag<BF, 64>& wnxt = i ? wA : wB;
-            if (i == 0) load_w<BF, 64>(R5_w1, (long)(c256 + 64) * 64 + KH, wnxt);
-            else load_w<BF, 64>(R5_w2, (long)col * 256 + 128 * grp + KH, wnxt);     // first dense_2 chunk of this group
+            WFrag<MM, 64>& wcur = i ? wB : wA;
+            WFrag<MM, 64>& wnxt = i ? wA : wB;
+            if (i == 0) load_w<MM, 64>(R5_w1, (long)(c256 + 64) * 64 + KH, wnxt);
+            else load_w<MM, 64>(R5_w2, (long)col * 256 + 128 * grp + KH, wnxt);     // first dense_2 chunk of this group
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mma_w<BF, 64>(sa, wcur, acc);
+            mma_w<MM, 64>(sa, wcur, acc);
             const float bias = ffn_bias[i];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -794,9 +853,9 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* sa = sU + (wm * 32 + l31) * FU + 128 * grp + KH;
-        load_w<BF, 64>(R6_w2, (long)col * 256 + 128 * grp + 64 + KH, wB);
-        mma_w<BF, 64>(sa, wA, acc);                          // chunk 0 of this group sits in wA
-        mma_w<BF, 64>(sa + 64, wB, acc);
+        load_w<MM, 64>(R6_w2, (long)col * 256 + 128 * grp + 64 + KH, wB);
+        mma_w<MM, 64>(sa, wA, acc);                          // chunk 0 of this group sits in wA
+        mma_w<MM, 64>(sa + 64, wB, acc);
         float* part = grp == 0 ? sX : sE;                    // sX / sE are dead: partial tiles
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
@@ -912,10 +971,12 @@ __device__ __forceinline__ void seq_partials_64(const f32x4 (&v)[N], float* cons
 // sources of the FrequencyLayer backward run one per group.
 // HEADP = TopBwdP: the block above is the one-row top block of the loss path; its backward runs first, inside this
 // kernel, on waves 0..3 (its dX tile stays in LDS), while waves 4..7 stage this block's gelu' tile.
-template <int DH, bool BF, class HEADP>
+template <int DH, bool BF, class HEADP, bool X3 = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
 #define PTYPE FusedBwdP
+    static_assert(!(BF && X3), "x3 products work on fp32 tensors");
+    constexpr int MM = X3 ? 2 : (BF ? 1 : 0);
     constexpr bool HEAD = IsTail<HEADP>::value;
     constexpr unsigned KOFF = (unsigned)((sizeof(FusedBwdP) + 7) & ~(size_t)7);     // kernarg offset of H_unused
     const auto R0_L = KARG(FusedBwdP, L);
@@ -944,7 +1005,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     const int b = blockIdx.x;
     const long tok0 = (long)b * L;
     const int col = wn * 32 + l31;
-    constexpr int KHM = BF ? 8 : 4;
+    constexpr int KHM = MM ? 8 : 4;
     const int KH = KHM * half;
     const int arow = (wm * 32 + l31) * FS + KH;
     float* const trash = KARG(FusedBwdP, trash) + 4 * lane;
@@ -988,8 +1049,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
             for (int i = 0; i < TOP_BWD_BARRIERS; ++i) lds_barrier();
         }
     }
-    WFrag<BF, 64> wA, wB;
-    load_wT<BF, 64, 256>(R1_w2, (long)KH * 256 + 128 * grp + col, wA);             // first dU block of this group
+    WFrag<MM, 64> wA, wB;
+    load_wT<MM, 64, 256>(R1_w2, (long)KH * 256 + 128 * grp + col, wA);             // first dU block of this group
     // stage A1's operands are requested BEFORE the u tile: loads return in issue order, so the LayerNorm row pass waits
     // only for them while the 64 KB of u are still in flight
     const f32x4 g = gld4(R1_ff_g + lc);
@@ -1071,19 +1132,19 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     const auto R2_w1 = KARG(FusedBwdP, w1);
     const auto R2_w2 = KARG(FusedBwdP, w2);
     // ---- stage A2: dU = (dT2 . W2) * gelu'(u) -> sdU (in place over the staged u tile): group g owns blocks 2g, 2g+1
-    if constexpr (!BF) {
+    if constexpr (MM == 0) {
         // fp32: block 1's MFMA chain (one accumulator, 64 cycles per dependent MFMA) is interleaved with block 0's
         // gelu' epilogue -- 2 MFMAs, then one output element (~30 VALU + an LDS round trip) -- so the vector work runs in
         // the issue slots the chain leaves empty instead of after it; both waves of a SIMD otherwise reach their MFMA
         // bursts and their epilogues together (lockstep) and the matrix pipe idles during every epilogue.
         const float* sa = sT + arow;
         const int c0 = (2 * grp) * 64 + col, c1 = c0 + 64;
-        load_wT<BF, 64, 256>(R2_w2, (long)KH * 256 + c1, wB);                          // block 1's weights
+        load_wT<MM, 64, 256>(R2_w2, (long)KH * 256 + c1, wB);                          // block 1's weights
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-        mma_w<BF, 64>(sa, wA, acc0);
-        load_wT<BF, 64, 64>(R2_w1, (long)(128 * grp + KH) * 64 + col, wA);             // first dH chunk of this group
+        mma_w<MM, 64>(sa, wA, acc0);
+        load_wT<MM, 64, 64>(R2_w1, (long)(128 * grp + KH) * 64 + col, wA);             // first dH chunk of this group
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const f32x4 a = ld4(sa + 8 * (r >> 1));
@@ -1105,14 +1166,14 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int blk = 2 * grp + i, c256 = blk * 64 + col;
-            WFrag<BF, 64>& wcur = i ? wB : wA;
-            WFrag<BF, 64>& wnxt = i ? wA : wB;
-            if (i == 0) load_wT<BF, 64, 256>(R2_w2, (long)KH * 256 + c256 + 64, wnxt);
-            else load_wT<BF, 64, 64>(R2_w1, (long)(128 * grp + KH) * 64 + col, wnxt);      // first dH chunk of this group
+            WFrag<MM, 64>& wcur = i ? wB : wA;
+            WFrag<MM, 64>& wnxt = i ? wA : wB;
+            if (i == 0) load_wT<MM, 64, 256>(R2_w2, (long)KH * 256 + c256 + 64, wnxt);
+            else load_wT<MM, 64, 64>(R2_w1, (long)(128 * grp + KH) * 64 + col, wnxt);      // first dH chunk of this group
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            mma_w<BF, 64>(sa, wcur, acc);
+            mma_w<MM, 64>(sa, wcur, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 32 + rho(r) + 4 * half;
@@ -1132,7 +1193,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     const auto R3_w1 = KARG(FusedBwdP, w1);
     const auto R3_wo = KARG(FusedBwdP, wo);
     // ---- stage A3: dH = dU . W1, K split: group g owns inner units [128g, 128g+128) -> partial tiles sG / sdF
-    WFrag<BF, 32> wO;
+    WFrag<MM, 32> wO;
     f32x4 pq[2], pk[2], pv[2], xa[2], xf[2];                 // stage B1's operands, prefetched below
     float ra[2], rf[2];
     {
@@ -1140,8 +1201,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* sa = sdU + (wm * 32 + l31) * FU + 128 * grp + KH;
-        load_wT<BF, 64, 64>(R3_w1, (long)(128 * grp + 64 + KH) * 64 + col, wB);
-        load_wT<BF, 32, 64>(R3_wo, (long)(32 * grp + KH) * 64 + col, wO);          // dense^T half for stage B2
+        load_wT<MM, 64, 64>(R3_w1, (long)(128 * grp + 64 + KH) * 64 + col, wB);
+        load_wT<MM, 32, 64>(R3_wo, (long)(32 * grp + KH) * 64 + col, wO);          // dense^T half for stage B2
         // stage B1's operands (q, k, v, xhat of both LayerNorms: 80 KB per sequence) are requested here, AFTER the weight
         // fragments this stage waits for (loads return in issue order), and land while the MFMAs below run
 #pragma unroll
@@ -1152,8 +1213,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
             xa[i] = ald4<BF>(KARG(FusedBwdP, xhat_a), ec); xf[i] = ald4<BF>(KARG(FusedBwdP, xhat_f), ec);
             ra[i] = gld(KARG(FusedBwdP, rstd_a) + tok0 + min(r, L - 1)); rf[i] = gld(KARG(FusedBwdP, rstd_f) + tok0 + min(r, L - 1));
         }
-        mma_w<BF, 64>(sa, wA, acc);                          // chunk 0 of this group sits in wA
-        mma_w<BF, 64>(sa + 64, wB, acc);
+        mma_w<MM, 64>(sa, wA, acc);                          // chunk 0 of this group sits in wA
+        mma_w<MM, 64>(sa + 64, wB, acc);
         float* part = grp == 0 ? sG : sdF;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
@@ -1232,7 +1293,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        mma_w<BF, 32>(sT + arow + 32 * grp, wO, acc);
+        mma_w<MM, 32>(sT + arow + 32 * grp, wO, acc);
         float* part = grp == 0 ? sG : sPm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
@@ -1280,7 +1341,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) da[r] = 0.f;
                 if (kt < nt && qt < nt)
-                    mma_ll<BF, DH>(sV + (32 * kt + l31) * FS + hc + KH, sG + query * FS + hc + KH, da);
+                    mma_ll<MM, DH>(sV + (32 * kt + l31) * FS + hc + KH, sG + query * FS + hc + KH, da);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1319,7 +1380,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
                     if (rt < nt) {
                         const float* bsrc = kind == 0 ? sK : kind == 1 ? sQ : sG;
                         const float* asrc = kind == 2 ? sPm : sS;
-                        if constexpr (BF) {
+                        if constexpr (MM != 0) {
 #pragma unroll 2
                             for (int s2 = 0; s2 < 2 * nt; ++s2) {          // K = 32*nt tokens, 16 per bf16 MFMA: k = 16 s2 + 8 h + j
                                 f32x4 a0, a1;
@@ -1334,7 +1395,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
                                 const float* bp = bsrc + (16 * s2 + KH) * FS + cc;
                                 f32x4 b0 = {bp[0], bp[FS], bp[2 * FS], bp[3 * FS]}, b1 = {bp[4 * FS], bp[5 * FS], bp[6 * FS], bp[7 * FS]};
                                 if (!cok) { b0 = f32x4{0, 0, 0, 0}; b1 = b0; }
-                                acc = mfma_bf16(pk8(a0, a1), pk8(b0, b1), acc);
+                                if constexpr (MM == 1) acc = mfma_bf16(pk8(a0, a1), pk8(b0, b1), acc);
+                                else acc = mfma_x3(split3(a0, a1), split3(b0, b1), acc);
                             }
                         } else {
 #pragma unroll 4
@@ -1402,11 +1464,11 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const long wofs = (long)KH * 64 + col;
-        WFrag<BF, 32> wk4;
-        if (grp == 0) { load_wT<BF, 64, 64>(R7_wq, wofs, wA); load_wT<BF, 32, 64>(R7_wk, wofs, wk4); }
-        else { load_wT<BF, 32, 64>(R7_wk, wofs + 32 * 64, wk4); load_wT<BF, 64, 64>(R7_wv, wofs, wA); }
-        mma_w<BF, 64>((grp == 0 ? sQ : sV) + arow, wA, acc);
-        mma_w<BF, 32>(sK + arow + 32 * grp, wk4, acc);
+        WFrag<MM, 32> wk4;
+        if (grp == 0) { load_wT<MM, 64, 64>(R7_wq, wofs, wA); load_wT<MM, 32, 64>(R7_wk, wofs, wk4); }
+        else { load_wT<MM, 32, 64>(R7_wk, wofs + 32 * 64, wk4); load_wT<MM, 64, 64>(R7_wv, wofs, wA); }
+        mma_w<MM, 64>((grp == 0 ? sQ : sV) + arow, wA, acc);
+        mma_w<MM, 32>(sK + arow + 32 * grp, wk4, acc);
         float* part = grp == 0 ? sG : sPm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define BSAREC_MAX_LAYERS 16
-#define BSAREC_ABI_VERSION 6
+#define BSAREC_ABI_VERSION 7
 
 /* Hyper-parameters the reference model reads from `args`
  * (src/utils.py:83-96; src/model/bsarec.py:71-88; src/model/_modules.py:79-87). */
@@ -66,6 +66,10 @@ typedef struct {
     int chain_kernels;  /* 1: the register-chain forward block kernel (fused_chain.h: lane = token, accumulators chained as MFMA
                          * operands, LDS weight ring) instead of the LDS-phase kernel (fused_layer.h) at the fused shape in
                          * fp32; measured equal in speed on MI355X, kept selectable */
+    int x3_products;    /* 1: the fused block kernels evaluate every fp32 product of their matrix multiplications on the bf16
+                         * matrix cores as six bf16 x bf16 partial products of the operands' exact three-way bf16 splits
+                         * (fp32 accumulation; error <= 2^-26 per product, below fp32 rounding; fp32 tensors, fp32 storage).
+                         * 0 (default): v_mfma_f32_32x32x2_f32.  Ignored under storage = 1 */
 } bsarec_config_t;
 
 /* The 19 tensors of one BSARecBlock, in state_dict order (+ the sibling model's filter weight)

@@ -162,16 +162,19 @@ def test_eval_mode_ignores_dropout_and_is_deterministic():
 
 @pytest.mark.parametrize("heads,L,B", [(1, 50, 9), (2, 50, 33), (4, 50, 5), (2, 64, 3), (2, 20, 7), (4, 33, 6), (2, 8, 4), (1, 5, 3),
                                        (2, 2, 6)])
-@pytest.mark.parametrize("fused", [2, 1, 0, 3, 4])
+@pytest.mark.parametrize("fused", [2, 1, 0, 3, 4, 5, 6])
 def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
     """hidden = 64, L <= 64 takes the fused per-sequence BSARecBlock kernels (fused = 2: with the top block of the
     loss path evaluated on its last row only, fused = 1: full block kernels for both layers; fused = 3 / 4: the same two
-    with the register-chain forward kernel of fused_chain.h, ``chain_kernels = 1``); the same cases are also forced through the generic tiled kernels (fused = 0).  All must match the oracle (dropout on, shared Philox
+    with the register-chain forward kernel of fused_chain.h, ``chain_kernels = 1``; fused = 5 / 6: the same two with every fp32
+    product of the block kernels evaluated on the bf16 matrix cores as six partial products of exact three-way bf16 splits,
+    ``x3_products = 1`` -- at the SAME fp32 gates); the same cases are also forced through the generic tiled kernels (fused = 0).  All must match the oracle (dropout on, shared Philox
     masks): loss and every parameter gradient; layer outputs on every row the variant produces."""
     from oracle import bsarec_oracle as O
     from bsarec_amd import _lib as Lb
     lib = Lb.load()
-    Lb.set_default_options(no_fused=0 if fused else 1, no_prune_top=0 if fused in (2, 3) else 1, chain_kernels=1 if fused >= 3 else 0)
+    Lb.set_default_options(no_fused=0 if fused else 1, no_prune_top=0 if fused in (2, 3, 5) else 1, chain_kernels=1 if fused in (3, 4) else 0,
+                           x3_products=1 if fused >= 5 else 0)
     try:
         cfg = O.Config(item_size=131, hidden_size=64, max_seq_length=L, num_hidden_layers=2, num_attention_heads=heads,
                        c=5, alpha=0.7, hidden_dropout_prob=0.4, attention_probs_dropout_prob=0.3)
@@ -197,7 +200,7 @@ def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
         plan = model._plan(B)
         for l in range(3):
             g, r = plan.view(Lb.BUF_LAYER_OUT, l, (B, L, 64)).cpu().numpy(), outs[l]
-            if fused in (2, 3) and l == 2:
+            if fused in (2, 3, 5) and l == 2:
                 g, r = g[:, -1], r[:, -1]
             assert np.isfinite(g).all()
             assert rel_l2(g, r) <= 2e-5, (l, rel_l2(g, r))
@@ -210,7 +213,7 @@ def test_fused_and_generic_paths_vs_oracle_d64(heads, L, B, fused):
                 assert np.abs(model.grad_views()[k].cpu().numpy()).max() <= 1e-5 and np.abs(G[k]).max() <= 1e-5, k
         check_grads(model, G, tol=2e-4, skip=skip)
     finally:
-        Lb.set_default_options(no_fused=0, no_prune_top=0, chain_kernels=0)
+        Lb.set_default_options(no_fused=0, no_prune_top=0, chain_kernels=0, x3_products=0)
 
 
 @pytest.mark.parametrize("layers,prune", [(3, 1), (3, 0), (1, 1)])
