@@ -127,6 +127,7 @@ EXPORTS = {
     "bsarec_shadow_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bsarec_plan_set_dense_grad_hook": (C.c_int, [C.c_void_p, HOOK, C.c_void_p, C.c_void_p]),
     "bsarec_buffer_is_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "bsarec_plan_is_fused": (C.c_int, [C.c_void_p]),
     "bsarec_plan_destroy": (None, [C.c_void_p]),
     "bsarec_buffer_offset": (C.c_long, [C.c_void_p, C.c_int, C.c_int]),
     "bsarec_step_begin": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -192,8 +192,11 @@ static int check_cfg(const bsarec_config_t& c) {
 
 static bool fused_shape_ok(const bsarec_config_t& c) {
     const int dh = c.hidden / c.heads;
-    return !c.no_fused && c.filter_kind == 0 && c.hidden_act == 0 && c.hidden == 64 && c.seq_len <= 64 && c.cutoff_bins <= FUSED_MAX_CB &&
-           (dh == 16 || dh == 32 || dh == 64);
+    if (c.no_fused || c.hidden_act != 0 || c.hidden != 64 || c.seq_len > 64 || !(dh == 16 || dh == 32 || dh == 64)) return false;
+    // filter_kind 1 (the sibling model FMLPRec: learnable complex filter over all L/2 + 1 bins, no attention branch) has its own
+    // instantiation of the block kernels, fp32 storage only
+    if (c.filter_kind == 1) return c.storage == 0 && c.alpha == 1.0f && c.cutoff_bins <= 36;
+    return c.cutoff_bins <= FUSED_MAX_CB;
 }
 
 static void derive(bsarec_plan& p) {
@@ -364,7 +367,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
         for (int l = 0; l < cfg->layers; ++l)
             add(p->part_cwL[l], p->G.layer[l].filter_cw, cfg->batch, (long)cfg->cutoff_bins * d * 2);
     p->jobs_per_layer = 19;
-    p->prune_ok = p->fused && cfg->layers >= 2 && !cfg->no_prune_top;
+    p->prune_ok = p->fused && cfg->layers >= 2 && !cfg->no_prune_top && cfg->filter_kind == 0;      // (the FMLPRec block keeps its full kernels)
     p->pruned = false;
     p->loss_kind = 0; p->bce_pos = nullptr; p->bce_neg = nullptr;
     std::vector<ReduceJob> jobs_pr = jobs;          // key_b is job 6, value_b job 8 of a layer's 19 (state_dict order)
@@ -437,6 +440,8 @@ extern "C" int bsarec_plan_set_dense_grad_hook(bsarec_plan_t* p, bsarec_hook_t h
     p->dense_hook = hook; p->dense_hook_user = user; p->lookup_grad = lookup_grad;
     return 0;
 }
+
+extern "C" int bsarec_plan_is_fused(const bsarec_plan_t* p) { return p && p->fused ? 1 : 0; }
 
 extern "C" int bsarec_buffer_is_bf16(const bsarec_plan_t* p, int buffer, int layer) {
     if (!p || !p->bf) return 0;
@@ -584,6 +589,16 @@ static int launch_fused_fwd(bsarec_plan& p, int l, bool tr, hipStream_t s, const
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l) : nullptr;
     TopFwdP TF;
     if (top_tail) fill_top_fwd(p, l + 1, tr, TF);
+    if (c.filter_kind == 1) {        // FMLPRec block: whole-spectrum complex filter + feed-forward (no attention branch)
+        F.filter_cw = w.filter_cw;
+        const size_t fsm = fused_fwd_smem_bytes();
+        static bool attr_fm = false;
+        if (!attr_fm) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_fwd_kernel<32, false, NoTail, false, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsm)); attr_fm = true; }
+        ProfScope prof(BSAREC_K_FUSED_FWD, s);
+        LAUNCH((fused_layer_fwd_kernel<32, false, NoTail, false, true>), dim3(c.batch), dim3(512), fsm, s, F, NoTail());
+        return (int)hipGetLastError();
+    }
     if (!p.bf && c.chain_kernels && !c.x3_products) {
         // register-chain forward (fused_chain.h): one wave per 16-token tile, two workgroup barriers
         const size_t csm = fused_chain_fwd_smem_bytes(top_tail);
@@ -648,6 +663,15 @@ static int launch_fused_bwd(bsarec_plan& p, int l, bool tr, const float* dY, flo
     F.trash = p.trash;
     F.stamps = p.stamps ? p.stamps + 32 * (2 * l + 1) : nullptr;
     const size_t smem = fused_bwd_smem_bytes();
+    if (c.filter_kind == 1) {
+        F.filter_cw = w.filter_cw; F.pcw = p.part_cwL[l];
+        static bool attr_fm = false;
+        if (!attr_fm) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<32, false, NoTail, false, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); attr_fm = true; }
+        ProfScope prof(BSAREC_K_FUSED_BWD, s);
+        LAUNCH((fused_layer_bwd_kernel<32, false, NoTail, false, true>), dim3(c.batch), dim3(512), smem, s, F, NoTail());
+        return (int)hipGetLastError();
+    }
 #define FUSED_BWD_CASE(DHV, BFV, X3V) { \
         static bool attr = false; \
         if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_bwd_kernel<DHV, BFV, NoTail, X3V>), \

@@ -39,6 +39,7 @@ struct FusedFwdP {
     const float *e_E, *e_pos, *e_g, *e_b; const int64_t* e_ids; GatherP e_gp; DropP e_drop; int e_V;
     float *e_X0, *e_xhat, *e_rstd; int* e_ids32;
     int xout_f32;           // bf16 storage: Xout is the LAST layer's output, which stays an fp32 tensor (logits / API)
+    const float* filter_cw; // FM instantiation only: FMLPRec's complex_weight [L/2 + 1][64][2] (re, im)
 };
 
 
@@ -391,12 +392,18 @@ __device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, f
 // TAILP = TopFwdP: the block above is the one-row top block of the loss path and runs as this kernel's tail -- the
 // output tile, the ids and the twiddle table stay in LDS, waves 4..7 exit, waves 0..3 carry on (one launch and the
 // top block's whole load phase saved).
-template <int DH, bool BF, class TAILP, bool X3 = false>
+template <int DH, bool BF, class TAILP, bool X3 = false, bool FM = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
 #define PTYPE FusedFwdP
     static_assert(!(BF && X3), "x3 products work on fp32 tensors");
     constexpr int MM = X3 ? 2 : (BF ? 1 : 0);       // product mode of the MFMA helpers (WFrag)
+    // FM: the sibling model FMLPRec's block (src/model/fmlprec.py:78-113) -- FilterLayer with the learnable complex filter
+    // y = irfft(rfft(x) * W) over ALL L/2 + 1 bins, LayerNorm(Drop(y) + x), then the same feed-forward; no attention branch
+    // (the reference's FMLPRecBlock has none).  Phases 1 (as the whole-spectrum DFT with the complex multiply), 5, 6, 7 run; the
+    // 36-bin twiddle / spectrum tables live in the attention tiles this variant never uses.
+    static_assert(!FM || (!BF && !X3 && !IsTail<TAILP>::value), "the FMLPRec block runs in fp32, without a top-block tail");
+    constexpr int MAXCB = FM ? 36 : FUSED_MAX_CB;
     constexpr bool TAIL = IsTail<TAILP>::value;
     constexpr unsigned KOFF = (unsigned)((sizeof(FusedFwdP) + 7) & ~(size_t)7);     // kernarg offset of T_unused
     const auto R0_L = KARG(FusedFwdP, L);
@@ -419,6 +426,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     float* sSpec = sTab + FUSED_MAX_CB * 128;   // FUSED_MAX_CB * 2 * 64
     float* sRed = sSpec + FUSED_MAX_CB * 128;   // softmax exchange: [4 pairs][2 key tiles][64 lanes]
     int* sIds = reinterpret_cast<int*>(sRed + 512);   // 64
+    if constexpr (FM) { sTab = sR; sSpec = sR + 2 * TS; }     // MAXCB * 128 floats each (<= 2 tiles); sU covers them only after the filter
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -443,7 +451,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     // order, so a load queued behind stores would wait for their write acknowledgements
     WFrag<MM, 64> wA, wB;
     float qkv_bias[3] = {0.f, 0.f, 0.f};
-    if (grp == 1) {
+    if (!FM && grp == 1) {
         load_w<MM, 64>(R1_wq, wrow, wA);
         qkv_bias[0] = gld(KARG(FusedFwdP, bq) + col); qkv_bias[1] = gld(KARG(FusedFwdP, bk) + col);
         qkv_bias[2] = gld(KARG(FusedFwdP, bv) + col);
@@ -551,7 +559,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
             }
         };
 #pragma unroll
-        for (int ch = 0; ch < FUSED_MAX_CB / 4; ++ch) {
+        for (int ch = 0; ch < MAXCB / 4; ++ch) {
             const int k0 = 4 * ch;
             if (k0 >= cb) break;
             if (grp == 0) {                          // accumulate 4 bins over this thread's rows
@@ -576,7 +584,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
                     st4(part + ((lr * 4 + j) * 2 + 0) * 64 + lc, re[j]);
                     st4(part + ((lr * 4 + j) * 2 + 1) * 64 + lc, im[j]);
                 }
-            } else if (ch == 0) qkv(std::integral_constant<int, 0>{});
+            } else if (!FM && ch == 0) qkv(std::integral_constant<int, 0>{});
             lds_barrier();
             if (grp == 0) {
                 for (int i = tid; i < 512; i += 256) {
@@ -588,15 +596,28 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
                         sSpec[(k0 + j) * 128 + rc] = acc;
                     }
                 }
-            } else if (ch == 0) qkv(std::integral_constant<int, 1>{});
+            } else if (!FM && ch == 0) qkv(std::integral_constant<int, 1>{});
             lds_barrier();
         }
-        if (grp == 1) qkv(std::integral_constant<int, 2>{});
+        if (!FM && grp == 1) qkv(std::integral_constant<int, 2>{});
+        if constexpr (FM) {      // Y_k = X_k W_k (complex, per bin and feature; complex_weight [cb][64][2], fmlprec.py:103-108)
+            const float* const cwp = KARG(FusedFwdP, filter_cw);
+            for (int i = tid; i < cb * 64; i += 512) {
+                const int k = i >> 6, c = i & 63;
+                const float xr = sSpec[k * 128 + c], xi = sSpec[k * 128 + 64 + c];
+                const float wr = gld(cwp + 2 * i), wi = gld(cwp + 2 * i + 1);
+                sSpec[k * 128 + c] = xr * wr - xi * wi;
+                sSpec[k * 128 + 64 + c] = xr * wi + xi * wr;
+            }
+            lds_barrier();
+        }
         // low-pass, beta^2 high-pass, dropout, residual, LayerNorm -> sD: group 0 takes rows 0..47 while group 1 is
         // still on the V projection, group 1 takes rows 48..63 afterwards
         {
             f32x4 b2 = gld4(R2_sqrt_beta + lc);
             b2 = b2 * b2;
+            if constexpr (FM) b2 = f32x4{0, 0, 0, 0};              // f = the filtered signal itself (no high-pass remainder)
+            float* const R2_hmix = KARG(FusedFwdP, hmix);
             const f32x4 g = gld4(R2_f_g + lc), be = gld4(R2_f_b + lc);
             const int rbeg = grp == 0 ? 0 : 48, rend = grp == 0 ? 48 : 64;
             for (int r0 = rbeg; r0 < rend; r0 += 16) {
@@ -620,16 +641,18 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
                     y = g * xh + be;
                     ast4<BF>(R2_xhat_f, e, xh);
                     if (R2_dsp) gst4(R2_dsp + e, y);
+                    if constexpr (FM) gst4(R2_hmix + e, y);          // alpha = 1: the block's mixed activation IS this output
                     if (lc == 0) gst(R2_rstd_f + (tok0 + t), rs);
                 }
-                st4(sD + t * FS + lc, y);
+                st4((FM ? sH : sD) + t * FS + lc, y);
             }
         }
     }
     // dense weights for phase 4 (this group's K half), held across the attention
     WFrag<MM, 32> wO;
-    load_w<MM, 32>(R2_wo, wrow + 32 * grp, wO);
+    if constexpr (!FM) load_w<MM, 32>(R2_wo, wrow + 32 * grp, wO);
     lds_barrier();
+    if constexpr (!FM) {
     // q, k, v -> global as whole rows, 16 B per lane (per-lane dword stores are store-issue bound)
     {
         const int lr = tid >> 4, lc = (tid & 15) << 2;
@@ -771,6 +794,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         }
     }
     lds_barrier();
+    }   // !FM: q / k / v write-out and the attention
 
     STAMP(4);
     const auto R4_a_b = KARG(FusedFwdP, a_b);
@@ -789,6 +813,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     {
         load_w<MM, 64>(R4_w1, (long)(128 * grp + col) * 64 + KH, wA);      // first dense_1 block of this group
         ffn_bias[0] = gld(KARG(FusedFwdP, b1) + 128 * grp + col); ffn_bias[1] = gld(KARG(FusedFwdP, b1) + 128 * grp + 64 + col);
+        if constexpr (!FM) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -796,11 +821,14 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         float* part = grp == 0 ? sQ : sK;                                  // sQ / sK are dead: partial tiles
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r];
+        }
     }
+    if constexpr (!FM) {
     lds_barrier();
     ln_rows_64<true, BF>(sQ, sK, R4_bo, sX, R4_drop_o, dseed, R4_a_g, R4_a_b, R4_eps, sD, R4_alpha, R4_oma, tok0, L, sH, R4_hmix, R4_xhat_a,
                      R4_rstd_a);
     lds_barrier();
+    }
 
     STAMP(5);
     const auto R5_b1 = KARG(FusedFwdP, b1);
@@ -916,6 +944,7 @@ struct FusedBwdP {
     // bottom block only (e_dz != null): the embedding front-end's backward rides in the epilogue --
     // y = Drop(LN(e)) (src/model/_abstract_model.py:14-24): de = LNbwd(dX * keep/(1-p)) -> e_dz instead of dX
     float* e_dz; const float *e_xhat, *e_rstd, *e_g; float *e_pg, *e_pb; DropP e_drop;
+    const float* filter_cw; float* pcw;     // FM instantiation only: FMLPRec's complex_weight [cb][64][2]; per-sequence d(complex_weight) [B][cb][64][2]
     const float* e_dx_extra;      // bottom block, optional: an upstream gradient of the EMBEDDING output itself (fp32 [B, L, 64]),
                                   // added to dX before the embedding LayerNorm backward (forward(all_sequence_output=True)[0])
 };
@@ -971,12 +1000,14 @@ __device__ __forceinline__ void seq_partials_64(const f32x4 (&v)[N], float* cons
 // sources of the FrequencyLayer backward run one per group.
 // HEADP = TopBwdP: the block above is the one-row top block of the loss path; its backward runs first, inside this
 // kernel, on waves 0..3 (its dX tile stays in LDS), while waves 4..7 stage this block's gelu' tile.
-template <int DH, bool BF, class HEADP, bool X3 = false>
+template <int DH, bool BF, class HEADP, bool X3 = false, bool FM = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
 #define PTYPE FusedBwdP
     static_assert(!(BF && X3), "x3 products work on fp32 tensors");
     constexpr int MM = X3 ? 2 : (BF ? 1 : 0);
+    // FM: backward of the sibling model FMLPRec's block (see the forward): stages A1..A3 (feed-forward), then its own tail
+    static_assert(!FM || (!BF && !X3 && !IsTail<HEADP>::value), "the FMLPRec block runs in fp32, without a top-block head");
     constexpr bool HEAD = IsTail<HEADP>::value;
     constexpr unsigned KOFF = (unsigned)((sizeof(FusedBwdP) + 7) & ~(size_t)7);     // kernarg offset of H_unused
     const auto R0_L = KARG(FusedBwdP, L);
@@ -1025,7 +1056,7 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     const auto R1_tw = KARG(FusedBwdP, tw);
     const auto R1_w2 = KARG(FusedBwdP, w2);
     const auto R1_xhat_ff = KARG(FusedBwdP, xhat_ff);
-    build_twiddle_table(R1_tw, L, cb, sTab);
+    if constexpr (!FM) build_twiddle_table(R1_tw, L, cb, sTab);      // (FM: all L/2 + 1 bins do not fit here; built in its tail)
     if constexpr (HEAD) {
         lds_barrier();                                  // the twiddle table is complete
         if (wave < 4) {
@@ -1202,16 +1233,19 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* sa = sdU + (wm * 32 + l31) * FU + 128 * grp + KH;
         load_wT<MM, 64, 64>(R3_w1, (long)(128 * grp + 64 + KH) * 64 + col, wB);
-        load_wT<MM, 32, 64>(R3_wo, (long)(32 * grp + KH) * 64 + col, wO);          // dense^T half for stage B2
+        if constexpr (!FM) load_wT<MM, 32, 64>(R3_wo, (long)(32 * grp + KH) * 64 + col, wO);          // dense^T half for stage B2
         // stage B1's operands (q, k, v, xhat of both LayerNorms: 80 KB per sequence) are requested here, AFTER the weight
         // fragments this stage waits for (loads return in issue order), and land while the MFMAs below run
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * i + lr;
             const long ec = (tok0 + min(r, L - 1)) * 64 + lc;
+            if constexpr (!FM) {
             pq[i] = ald4<BF>(KARG(FusedBwdP, q), ec); pk[i] = ald4<BF>(KARG(FusedBwdP, k), ec); pv[i] = ald4<BF>(KARG(FusedBwdP, v), ec);
-            xa[i] = ald4<BF>(KARG(FusedBwdP, xhat_a), ec); xf[i] = ald4<BF>(KARG(FusedBwdP, xhat_f), ec);
-            ra[i] = gld(KARG(FusedBwdP, rstd_a) + tok0 + min(r, L - 1)); rf[i] = gld(KARG(FusedBwdP, rstd_f) + tok0 + min(r, L - 1));
+            xa[i] = ald4<BF>(KARG(FusedBwdP, xhat_a), ec); ra[i] = gld(KARG(FusedBwdP, rstd_a) + tok0 + min(r, L - 1));
+            }
+            xf[i] = ald4<BF>(KARG(FusedBwdP, xhat_f), ec);
+            rf[i] = gld(KARG(FusedBwdP, rstd_f) + tok0 + min(r, L - 1));
         }
         mma_w<MM, 64>(sa, wA, acc);                          // chunk 0 of this group sits in wA
         mma_w<MM, 64>(sa + 64, wB, acc);
@@ -1222,6 +1256,158 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     lds_barrier();
 
     STAMP(3);
+    if constexpr (FM) {
+        // ================= FMLPRec tail: filter LayerNorm backward, complex-filter backward =================
+        // y = irfft(rfft(x) * W), h = LN_f(Drop(y) + x) is the block's mixed activation (no attention branch).  With D the
+        // spectrum of dF = Drop'(dz_f):  dX = dz_f + inverse(D conj(W)),  dW_k = (w_k / L) conj(X_k) D_k per sequence
+        // (w_k = 1 for DC / Nyquist, else 2) -- the formulas of freq_bwd_kernel (kernels.h), all L/2 + 1 bins.
+        // LDS: T0 dz_f | T1 x | T2 / T3 DFT partials of group 0 / 1 | T4-T5 twiddles | T6-T7 spectra [2][cb][2][64] | T8 dF
+        float* const sXin = sT;  float* const sdFm = sPm;  float* const tab = sV;  float* const spec = sG;
+        const DropP drop_f = KARG(FusedBwdP, drop_f);
+        const f32x4 gf = gld4(KARG(FusedBwdP, f_g) + lc);
+        const float* const Xg = KARG(FusedBwdP, X);
+        f32x4 sgf = {0, 0, 0, 0}, sbf = sgf;
+        const f32x4 z4 = {0, 0, 0, 0};
+        f32x4 dzf2[2], dF2[2], x2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
+            const bool ok = r < L;
+            const long e = (tok0 + r) * 64 + lc;
+            if (!ok) { xf[i] = z4; rf[i] = 0.f; }
+            f32x4 dh = z4;
+            if (ok) dh = ld4(sG + r * FS + lc) + ld4(sdF + r * FS + lc) + ld4(sAcc + r * FS + lc);
+            const f32x4 g2 = dh * gf;                                  // alpha = 1: the whole gradient goes to the filter branch
+            const float n1 = group_sum<16>(g2.x + g2.y + g2.z + g2.w) * (1.0f / 64.0f);
+            const float n2 = group_sum<16>(g2.x * xf[i].x + g2.y * xf[i].y + g2.z * xf[i].z + g2.w * xf[i].w) * (1.0f / 64.0f);
+            dzf2[i] = rf[i] * (g2 - n1 - xf[i] * n2);
+            sgf += dh * xf[i]; sbf += dh;
+            dF2[i] = z4; x2[i] = z4;
+            if (ok) {
+                dF2[i] = dzf2[i] * drop_mult4(drop_f, dseed, (uint64_t)e >> 2);
+                x2[i] = gld4(Xg + e);
+                // the attention tensors exist in the arena (the sibling model reuses BSARec's layout): their weight-gradient
+                // operands are exact zeros
+                gst4(KARG(FusedBwdP, dO) + e, z4); gst4(KARG(FusedBwdP, dq) + e, z4);
+                gst4(KARG(FusedBwdP, dk) + e, z4); gst4(KARG(FusedBwdP, dv) + e, z4);
+            }
+        }
+        lds_barrier();                                                 // every read of the dH partial tiles (sG, sdF) is done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 32 * i + lr;
+            st4(sAcc + r * FS + lc, dzf2[i]);
+            st4(sdFm + r * FS + lc, dF2[i]);
+            st4(sXin + r * FS + lc, x2[i]);
+        }
+        build_twiddle_table(R1_tw, L, cb, tab);
+        {
+            const f32x4 pv[4] = {z4, z4, sgf, sbf};
+            float* const pr[4] = {sQ, sQ + 2048, sK, sK + 2048};
+            float* const pd[4] = {KARG(FusedBwdP, pg_a) + (long)b * 64, KARG(FusedBwdP, pb_a) + (long)b * 64,
+                                  KARG(FusedBwdP, pg_f) + (long)b * 64, KARG(FusedBwdP, pb_f) + (long)b * 64};
+            seq_partials_64<4>(pv, pr, pd);                            // (two barriers inside: tiles and table are visible after it)
+        }
+        lds_barrier();
+        // spectra: group 0 transforms x, group 1 transforms dF; 2 bins per pass (partials [16 row groups][2][2][64] per group)
+        {
+            const int lr16 = (tid & 255) >> 4;
+            const float* srcT = grp == 0 ? sXin : sdFm;
+            float* part = grp == 0 ? sQ : sK;
+            float* specg = spec + grp * cb * 128;
+            for (int k0 = 0; k0 < cb; k0 += 2) {
+                f32x4 re[2], im[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { re[j] = z4; im[j] = z4; }
+#pragma unroll
+                for (int r0 = 0; r0 < 64; r0 += 16) {
+                    const int t = r0 + lr16;
+                    if (t < L) {
+                        const f32x4 x = ld4(srcT + t * FS + lc);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            if (k0 + j < cb) {
+                                const float c = tab[2 * ((k0 + j) * 64 + t)], sn = tab[2 * ((k0 + j) * 64 + t) + 1];
+                                re[j] += x * c; im[j] -= x * sn;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    st4(part + ((lr16 * 2 + j) * 2 + 0) * 64 + lc, re[j]);
+                    st4(part + ((lr16 * 2 + j) * 2 + 1) * 64 + lc, im[j]);
+                }
+                lds_barrier();
+                {
+                    const int i = tid & 255;                           // 2 bins x (re | im) x 64 = 256 sums per group
+                    const int j = i >> 7;
+                    if (k0 + j < cb) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int gq = 0; gq < 16; ++gq) acc += part[gq * 256 + i];
+                        specg[(k0 + j) * 128 + (i & 127)] = acc;
+                    }
+                }
+                lds_barrier();
+            }
+        }
+        {   // dW partials of this sequence, D <- D conj(W)
+            const float* const cwp = KARG(FusedBwdP, filter_cw);
+            float* const pcw = KARG(FusedBwdP, pcw) + (long)b * cb * 128;
+            float* const sDs = spec + cb * 128;
+            for (int i = tid; i < cb * 64; i += 512) {
+                const int k = i >> 6, c = i & 63;
+                const float xr = spec[k * 128 + c], xi = spec[k * 128 + 64 + c];
+                const float dr = sDs[k * 128 + c], di = sDs[k * 128 + 64 + c];
+                const float wr = gld(cwp + 2 * i), wi = gld(cwp + 2 * i + 1);
+                const float wl = ((k == 0 || 2 * k == L) ? 1.0f : 2.0f) / (float)L;
+                gst(pcw + 2 * i, wl * (dr * xr + di * xi));
+                gst(pcw + 2 * i + 1, wl * (di * xr - dr * xi));
+                sDs[k * 128 + c] = dr * wr + di * wi;
+                sDs[k * 128 + 64 + c] = di * wr - dr * wi;
+            }
+        }
+        lds_barrier();
+        {   // dX = dz_f + inverse(D conj(W)); bottom block: the embedding front-end's backward on the finished row
+            float* const e_dz = KARG(FusedBwdP, e_dz);
+            const float* const e_xhat = KARG(FusedBwdP, e_xhat);
+            const float* const e_rstd = KARG(FusedBwdP, e_rstd);
+            const DropP e_drop = KARG(FusedBwdP, e_drop);
+            const float* const e_dx_extra = KARG(FusedBwdP, e_dx_extra);
+            float* const dXg = KARG(FusedBwdP, dX);
+            f32x4 g0 = z4, sg0 = z4, sb0 = z4;
+            if (e_dz) g0 = gld4(KARG(FusedBwdP, e_g) + lc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int t = 32 * i + lr;
+                const bool ok = t < L;
+                const long e = (tok0 + t) * 64 + lc;
+                f32x4 dx = z4, xh = z4;
+                float rs = 0.f;
+                if (ok) {
+                    dx = ld4(sAcc + t * FS + lc) + lowpass_tab(spec + cb * 128, t, lc, L, cb, tab);
+                    if (e_dx_extra) dx += gld4(e_dx_extra + e);
+                    if (e_dz) { xh = gld4(e_xhat + e); rs = gld(e_rstd + tok0 + t); dx = dx * drop_mult4(e_drop, dseed, (uint64_t)e >> 2); }
+                    else gst4(dXg + e, dx);
+                }
+                if (e_dz) {
+                    const f32x4 gg = dx * g0;
+                    const float m1 = group_sum<16>(gg.x + gg.y + gg.z + gg.w) * (1.0f / 64.0f);
+                    const float m2 = group_sum<16>(gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w) * (1.0f / 64.0f);
+                    if (ok) gst4(e_dz + e, rs * (gg - m1 - xh * m2));
+                    sg0 += dx * xh; sb0 += dx;
+                }
+            }
+            float* const pbeta = KARG(FusedBwdP, pbeta) + (long)b * 64;
+            if (e_dz) {
+                const f32x4 pv[3] = {z4, sg0, sb0};                    // (FMLPRec has no sqrt_beta: its partial is zero)
+                float* const pr[3] = {sQ, sQ + 2048, sK};
+                float* const pd[3] = {pbeta, KARG(FusedBwdP, e_pg) + (long)b * 64, KARG(FusedBwdP, e_pb) + (long)b * 64};
+                seq_partials_64<3>(pv, pr, pd);
+            } else if (tid < 64) gst(pbeta + tid, 0.f);
+        }
+        return;
+    }
     const auto R4_a_g = KARG(FusedBwdP, a_g);
     const auto R4_alpha = KARG(FusedBwdP, alpha);
     const auto R4_dO = KARG(FusedBwdP, dO);

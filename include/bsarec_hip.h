@@ -136,6 +136,9 @@ int bsarec_shadow_refresh(bsarec_plan_t *plan, void *stream);
 /* Element type of a named workspace buffer under this plan: 0 = fp32, 1 = bf16 (cfg.storage = 1: every saved
  * activation of the block stack except the last layer's output; logits, loss and the statistics stay fp32). */
 int bsarec_buffer_is_bf16(const bsarec_plan_t *plan, int buffer, int layer);
+
+/* 1 if the plan resolved to the fused per-sequence block kernels (hidden = 64, L <= 64, ...), 0 for the generic tiled kernels. */
+int bsarec_plan_is_fused(const bsarec_plan_t *plan);
 void bsarec_plan_destroy(bsarec_plan_t *plan);
 
 /* Data-parallel bucketing: the dense part of the item-table gradient, dE = dlogits^T . h_last, is complete

@@ -1,4 +1,4 @@
-"""Sibling model FMLPRec (the learnable complex filter) on the generic kernels: the oracle (alpha = 1,
+"""Sibling model FMLPRec (the learnable complex filter), fused per-sequence kernels and generic kernels: the oracle (alpha = 1,
 complex filter, log-sigmoid head) against golden vectors made by importing the reference's FMLPRecModel
 (tests/golden/make_golden_fmlprec.py), and the HIP path against both."""
 import argparse
@@ -47,12 +47,22 @@ def test_oracle_fmlprec_vs_reference_golden(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("name", CASES)
-def test_hip_fmlprec_vs_reference_golden(name):
-    """HIP path (generic kernels, filter_kind = 1): layer outputs, loss, all 22 gradients incl. complex_weight, and three
-    Adam steps against the imported reference."""
+def test_hip_fmlprec_vs_reference_golden(name, fused):
+    """HIP path (filter_kind = 1): layer outputs, loss, all 22 gradients incl. complex_weight, and three Adam steps against
+    the imported reference.  fused = 1: the FMLPRec instantiation of the per-sequence block kernels (whole-spectrum complex
+    filter in LDS + feed-forward, no attention branch; round 3); fused = 0: the generic tiled kernels."""
     torch = pytest.importorskip("torch")
-    from bsarec_amd import FMLPRecModel, MODEL_DICT
+    from bsarec_amd import FMLPRecModel, MODEL_DICT, _lib as Lb
+    old = Lb.set_default_options(no_fused=1 - fused)
+    try:
+        _hip_fmlprec_vs_reference_golden(name, fused, torch, FMLPRecModel, MODEL_DICT, Lb)
+    finally:
+        Lb.set_default_options(**old)
+
+
+def _hip_fmlprec_vs_reference_golden(name, fused, torch, FMLPRecModel, MODEL_DICT, Lb):
     z, cfg = load(name)
     a = argparse.Namespace(hidden_act="gelu", batch_size=8, c=3, seed=1, **cfg)
     m = MODEL_DICT["fmlprec"](args=a)
@@ -85,6 +95,57 @@ def test_hip_fmlprec_vs_reference_golden(name):
         got, want = sd[k].cpu().numpy(), z["a/" + k]
         bad = np.abs(got - want) > 2e-5
         assert bad.mean() <= 2e-3, (k, bad.mean(), np.abs(got - want).max())
+    # the path under test was the one asked for (the plan says which kernels it resolved to)
+    plan = m._plan(ids.shape[0])
+    assert bool(Lb.load().bsarec_plan_is_fused(plan.handle)) == bool(fused)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("name,B", [("A_d64_L50", 19), ("B_d64_L21", 7)])
+def test_hip_fmlprec_dropout_step_vs_oracle(name, B, fused):
+    """Dropout ON (shared Philox masks), ragged batch incl. an all-padding and a full row: loss and every gradient
+    (complex_weight too) against the oracle, fused and generic kernels, even and odd L."""
+    torch = pytest.importorskip("torch")
+    from oracle import bsarec_oracle as O
+    from bsarec_amd import MODEL_DICT, _lib as Lb
+    old = Lb.set_default_options(no_fused=1 - fused)
+    try:
+        z, cfg = load(name)
+        cfg = dict(cfg, hidden_dropout_prob=0.4, attention_probs_dropout_prob=0.3)
+        L, V = cfg["max_seq_length"], cfg["item_size"]
+        c = O.Config(item_size=V, hidden_size=cfg["hidden_size"], max_seq_length=L, num_hidden_layers=cfg["num_hidden_layers"],
+                     num_attention_heads=cfg["num_attention_heads"], c=3, alpha=1.0, hidden_dropout_prob=0.4,
+                     attention_probs_dropout_prob=0.3)
+        P = O.init_params(c, seed=1)
+        keys = [k[2:] for k in z.files if k.startswith("p/")]
+        for k in keys:
+            P[to_bsarec_key(k)] = z["p/" + k]
+        rng = np.random.default_rng(B)
+        ids = np.zeros((B, L), dtype=np.int64)
+        for b in range(B):
+            n = 0 if b == 0 else (L if b == 1 else int(rng.integers(1, L + 1)))
+            if n:
+                ids[b, L - n:] = rng.integers(1, V, size=n)
+        pos = rng.integers(1, V, size=B).astype(np.int64)
+        neg = rng.integers(1, V, size=B).astype(np.int64)
+        a = argparse.Namespace(hidden_act="gelu", batch_size=8, c=3, seed=1, **cfg)
+        m = MODEL_DICT["fmlprec"](args=a)
+        m.load_state_dict({k: torch.from_numpy(z["p/" + k]) for k in keys})
+        m = m.cuda()
+        m.train()
+        m.set_seed(321)
+        loss = m.calculate_loss(torch.from_numpy(ids).cuda(), torch.from_numpy(pos).cuda(), torch.from_numpy(neg).cuda(), None, None)
+        loss.backward()
+        oloss, _, G, _ = O.loss_and_grads(P, c, ids, None, O.DropoutSpec(True, 321, 1), head=O.fmlp_head(pos, neg))
+        assert abs(loss.item() - oloss) <= 5e-6 * abs(oloss), (loss.item(), oloss)
+        got = m.grad_views()
+        for k in keys:
+            kk = to_bsarec_key(k)
+            assert rel_l2(got[kk].cpu().numpy(), G[kk]) <= 2e-4, (k, rel_l2(got[kk].cpu().numpy(), G[kk]))
+        assert bool(Lb.load().bsarec_plan_is_fused(m._plan(B).handle)) == bool(fused)
+    finally:
+        Lb.set_default_options(**old)
 
 
 @pytest.mark.gpu
