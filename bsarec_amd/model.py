@@ -700,7 +700,8 @@ class FMLPRecModel(BSARecModel):
     The attention tensors and sqrt_beta exist in the arena, receive exactly zero gradient and are neither saved nor
     loaded; state_dict uses the reference's names (``...layer.complex_weight``, ``...layer.LayerNorm.*``; 4 + 9 N keys).
     Loss head: -log(sigmoid(x_pos) + 1e-24) - log(1 - sigmoid(x_neg) + 1e-24), mean over the batch (fmlprec.py:41-62).
-    Runs on the generic tiled kernels (the fused per-sequence kernels implement BSARec's filter only)."""
+    At the fused shape (hidden = 64, L <= 64) the block runs in the FM instantiation of the per-sequence block kernels (filter
+    + feed-forward, no attention branch); elsewhere on the generic tiled kernels."""
 
     needs_negatives = True
 
