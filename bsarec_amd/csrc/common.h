@@ -168,6 +168,15 @@ __device__ __forceinline__ void halves_of(float v, float& lo, float& hi) {
 }
 __device__ __forceinline__ float xor32_sum(float v) { float lo, hi; halves_of(v, lo, hi); return lo + hi; }
 __device__ __forceinline__ float xor32_max(float v) { float lo, hi; halves_of(v, lo, hi); return fmaxf(lo, hi); }
+// sum / max over the four lanes n, n + 16, n + 32, n + 48 (v_permlane16_swap: odd rows of the first operand <-> even rows of
+// the second; v_permlane32_swap: upper half of the first <-> lower half of the second)
+__device__ __forceinline__ void rows_of(float v, float& a_, float& b_) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a_ = __builtin_bit_cast(float, a); b_ = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float quad_rows_sum(float v) { float a, b; rows_of(v, a, b); return xor32_sum(a + b); }
+__device__ __forceinline__ float quad_rows_max(float v) { float a, b; rows_of(v, a, b); return xor32_max(fmaxf(a, b)); }
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
     v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]

@@ -33,15 +33,7 @@
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// sum / max over the four lanes n, n + 16, n + 32, n + 48 (v_permlane16_swap: odd rows of the first operand <-> even rows of
-// the second; v_permlane32_swap: upper half of the first <-> lower half of the second; see halves_of in common.h)
-__device__ __forceinline__ void rows_of(float v, float& a_, float& b_) {
-    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    a_ = __builtin_bit_cast(float, a); b_ = __builtin_bit_cast(float, b);
-}
-__device__ __forceinline__ float quad_rows_sum(float v) { float a, b; rows_of(v, a, b); return xor32_sum(a + b); }
-__device__ __forceinline__ float quad_rows_max(float v) { float a, b; rows_of(v, a, b); return xor32_max(fmaxf(a, b)); }
+// (rows_of / quad_rows_sum / quad_rows_max: common.h)
 
 // LayerNorm of a token held as 4 slabs (16 registers x 4 lanes)
 __device__ __forceinline__ void ln_slabs(const f32x4 (&v)[4], float eps, f32x4 (&xh)[4], float& rstd) {

@@ -65,6 +65,25 @@ __device__ __forceinline__ T kernarg_field(unsigned byte_off) {
     return GlobalPtr<T>::fix(x.v);
 }
 #define KARG(S, f) kernarg_field<decltype(S::f)>((unsigned)offsetof(S, f))
+// Touch every 64-byte line of the kernarg segment: the first scalar load of a line after a launch misses the scalar cache
+// all the way to memory, and a kernel that reads its ~40 pointers phase by phase pays that miss again and again on its
+// dependent chain.  Wave w requests lines w, w + 8, w + 16; the values are handed to kernarg_touch_done() at a point where
+// the wave waits for scalar loads anyway (an s_load whose destination the compiler does not track must never be left
+// in flight: the late write would land in a register that has been given to something else).
+struct KernargTouch { unsigned v[3]; };
+template <unsigned BYTES>
+__device__ __forceinline__ KernargTouch kernarg_touch() {
+    static_assert(BYTES <= 24 * 64, "three lines per wave");
+    typedef __attribute__((address_space(4))) const unsigned* kwords_t;
+    kwords_t base = (kwords_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr unsigned LAST = (BYTES - 4) / 64;                     // last line of the segment
+    KernargTouch t;
+#pragma unroll
+    for (unsigned j = 0; j < 3; ++j) t.v[j] = base[16 * min(8 * j + wave, LAST)];
+    return t;
+}
+__device__ __forceinline__ void kernarg_touch_done(const KernargTouch& t) { asm volatile("" :: "s"(t.v[0]), "s"(t.v[1]), "s"(t.v[2])); }
 #define STAMP(i) do { long long* st_ = KARG(PTYPE, stamps); if (st_ && blockIdx.x == 0 && threadIdx.x == 0) st_[i] = clock64(); } while (0)
 
 
@@ -126,8 +145,12 @@ template <bool BF> __device__ __forceinline__ void ast(float* base, long e, floa
 
 
 // ---- pruned DFT with a per-workgroup twiddle table tab[k][t] = (cos, sin)(2 pi k t / L), k < cb, t < 64
-__device__ __forceinline__ void build_twiddle_table(const float* __restrict__ tw, int L, int cb, float* __restrict__ tab) {
-    for (int i = threadIdx.x; i < cb * 64; i += blockDim.x) {
+// (first / nthr: the threads that build it -- by default the whole workgroup)
+__device__ __forceinline__ void build_twiddle_table(const float* __restrict__ tw, int L, int cb, float* __restrict__ tab,
+                                                    int first = 0, int nthr = 0) {
+    if (nthr == 0) nthr = blockDim.x;
+    if ((int)threadIdx.x < first) return;
+    for (int i = threadIdx.x - first; i < cb * 64; i += nthr) {
         const int k = i >> 6, t = i & 63;
         float c = 0.f, s = 0.f;
         if (t < L) { const int a = (int)((unsigned)(k * t) % (unsigned)L); c = gld(tw + 2 * a); s = gld(tw + 2 * a + 1); }
@@ -375,11 +398,24 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
 template <class T> struct IsTail { static constexpr bool value = true; };
 template <> struct IsTail<NoTail> { static constexpr bool value = false; };
 // ... and its backward as the head of this block's backward kernel.  Waves 4..7 of that kernel execute exactly
-// TOP_BWD_BARRIERS barriers while waves 0..3 run top_bwd_body (which contains that many, all unconditional).
+// TOP_BWD_BARRIERS barriers (top_bwd_help_a + top_bwd_help_b: the two wide steps they take over) while waves 0..3 run
+// top_bwd_body<.., HELPED = true> (which contains that many, all unconditional).
 constexpr int TOP_BWD_BARRIERS = 11;
-template <int DH, bool BF, unsigned KOFF>
-__device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, float* sK, float* sV, const float* sTab, float* sVec,
-                                             float* sDX);
+struct TopBwdRegs {                                 // what top_bwd_prefetch requests at the top of the kernel (wave 0, lane = column)
+    float sl[32];                                   // the first 32 split-K slabs of the upstream gradient (0 past dh_nsplit)
+    float xh_ff, g_ff, rs_ff, xa, xf, g_a, g_f, rs_a, rs_f, bt, low_l, x_l, q_l;
+    f32x4 tq[16];                                   // waves 1..3 (fused head only): the x / k / v tile, one per wave
+    float p_pre;                                    // waves < heads (fused head only): the probability row of the last query
+};
+struct TopBwdHelpRegs { f32x4 w2c[16], w1c[16], u4; };      // waves 4..7: dense_2 / dense_1 columns, gelu' input of their units
+template <bool BF, unsigned KOFF> __device__ __forceinline__ void top_bwd_prefetch(TopBwdRegs& R);
+template <bool BF, unsigned KOFF> __device__ __forceinline__ void top_bwd_prefetch_tile(TopBwdRegs& R);
+template <bool BF, unsigned KOFF> __device__ __forceinline__ void top_bwd_help_prefetch(TopBwdHelpRegs& H);
+template <int DH, bool BF, unsigned KOFF, bool HELPED>
+__device__ __forceinline__ void top_bwd_body(const TopBwdRegs& R, const DropSeed& dseed, float* sX, float* sK, float* sV, const float* sTab,
+                                             float* sVec, float* sDX);
+template <bool BF, unsigned KOFF> __device__ __forceinline__ void top_bwd_help_a(const TopBwdHelpRegs& H, float* sVec);
+template <int DH, bool BF, unsigned KOFF> __device__ __forceinline__ void top_bwd_help_b(const float* sX, float* sVec, const float* gu, f32x4 (&uw)[16]);
 
 
 // Forward: 8 waves = 2 groups of 4 (each group tiles 64 tokens x 64 features as 2 x 2 waves), two waves per SIMD
@@ -1042,7 +1078,23 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     float* const trash = KARG(FusedBwdP, trash) + 4 * lane;
 
     STAMP(0);
-    const DropSeed dseed = drop_seed(KARG(FusedBwdP, drop_f));     // first loads of the kernel
+    const KernargTouch ktouch = kernarg_touch<KOFF + (unsigned)sizeof(HEADP)>();
+    // first loads of the kernel: everything the head reads that does not depend on its own results -- wave 0 the operands of
+    // the chain that opens it, waves 1..3 a tile each, waves 4..7 their weight columns -- so that these ~180 KB cross the CU's
+    // memory pipeline under the twiddle-table build, not between the head's barriers
+    TopBwdRegs HR;
+    TopBwdHelpRegs HH;
+    if constexpr (HEAD) {
+        if (wave == 0) top_bwd_prefetch<BF, KOFF>(HR);
+        else if (wave < 4) {
+            // wave 3 (the one without a dropout multiplier to evaluate in the head's first step) builds the twiddle table, ahead
+            // of its tile request: a load behind 16 KB of tile rows would not return for thousands of cycles
+            if (wave == 3) build_twiddle_table(KARG(FusedBwdP, tw), L, cb, sTab, 192, 64);
+            top_bwd_prefetch_tile<BF, KOFF>(HR);
+        } else top_bwd_help_prefetch<BF, KOFF>(HH);
+    }
+    const DropSeed dseed = drop_seed(KARG(FusedBwdP, drop_f));
+    kernarg_touch_done(ktouch);
     const auto R1_dT = KARG(FusedBwdP, dT);
     const auto R1_dY = KARG(FusedBwdP, dY);
     const auto R1_dh_nsplit = KARG(FusedBwdP, dh_nsplit);
@@ -1056,28 +1108,25 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     const auto R1_tw = KARG(FusedBwdP, tw);
     const auto R1_w2 = KARG(FusedBwdP, w2);
     const auto R1_xhat_ff = KARG(FusedBwdP, xhat_ff);
-    if constexpr (!FM) build_twiddle_table(R1_tw, L, cb, sTab);      // (FM: all L/2 + 1 bins do not fit here; built in its tail)
+    if constexpr (!FM && !HEAD) build_twiddle_table(R1_tw, L, cb, sTab);      // (FM: all L/2 + 1 bins do not fit here; built in its tail)
     if constexpr (HEAD) {
-        lds_barrier();                                  // the twiddle table is complete
+        // (no barrier here: the head first reads the twiddle table after its third barrier, and every wave has written its
+        // part of the table before it reaches the head's first one)
         if (wave < 4) {
             // top block's tiles alias T6..T8, its row vectors T0, its dX tile T1 (= this block's dY); T2..T5 stay free for
             // the gelu' tile the other waves are staging
-            top_bwd_body<DH, BF, KOFF>(dseed, sG, sdF, sPm, sTab, sAcc, sT);
+            top_bwd_body<DH, BF, KOFF, true>(HR, dseed, sG, sdF, sPm, sTab, sAcc, sT);
         } else {
-            const float* gu = KARG(FusedBwdP, u);
+            top_bwd_help_a<BF, KOFF>(HH, sAcc);
+            // this block's gelu' tile trickles into registers during the head's narrow steps (top_bwd_help_b) and is stored
+            // once the head is through: stage A1's barrier below orders the stores before stage A2
             f32x4 uw[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int idx = (tid - 256) + i * 256, r = idx >> 6, c4 = (idx & 63) << 2;
-                uw[i] = ald4<BF>(gu, (tok0 + min(r, L - 1)) * 256 + c4);
-            }
+            top_bwd_help_b<DH, BF, KOFF>(sG, sAcc, KARG(FusedBwdP, u), uw);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int idx = (tid - 256) + i * 256, r = idx >> 6, c4 = (idx & 63) << 2;
                 st4(sdU + r * FU + c4, r < L ? uw[i] : f32x4{0, 0, 0, 0});
             }
-#pragma unroll 1
-            for (int i = 0; i < TOP_BWD_BARRIERS; ++i) lds_barrier();
         }
     }
     WFrag<MM, 64> wA, wB;

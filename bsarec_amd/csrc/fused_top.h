@@ -77,6 +77,28 @@ __device__ __forceinline__ float gemv_cols_dot(const float (&wv)[KC], const floa
     return acc;
 }
 
+// The same transposed product with FOUR adjacent outputs per lane: lane (g = lane & 15, kq = lane >> 4) of a wave covers
+// outputs i0 + 4 g .. + 3 over the inner indices k0 + 16 kq .. + 15, 16 dwordx4 loads (a wave instruction reads four 256-byte
+// row segments) instead of 64 dword loads for the same 64 x 64 block of W; the four kq partial sums of an output meet by
+// two lane swaps (quad_rows_sum).  Every lane returns the complete sums of its four outputs.
+__device__ __forceinline__ void gemv_cols4_load(const float* __restrict__ W, int ldw, int k0, int i0, f32x4 (&wv)[16]) {
+    const int lane = threadIdx.x & 63;
+    const float* w = W + (long)(k0 + 16 * (lane >> 4)) * ldw + i0 + 4 * (lane & 15);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wv[k] = gld4(w + (long)k * ldw);
+}
+__device__ __forceinline__ f32x4 gemv_cols4_dot(const f32x4 (&wv)[16], const float* __restrict__ sx, int k0) {
+    const int lane = threadIdx.x & 63;
+    const float* x = sx + k0 + 16 * (lane >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+        const f32x4 xv = ld4(x + k);
+        acc += wv[k] * xv.x + wv[k + 1] * xv.y + wv[k + 2] * xv.z + wv[k + 3] * xv.w;
+    }
+    return f32x4{quad_rows_sum(acc.x), quad_rows_sum(acc.y), quad_rows_sum(acc.z), quad_rows_sum(acc.w)};
+}
+
 // LayerNorm of one 64-wide row held one column per lane of a wave
 __device__ __forceinline__ void ln_row(float v, float eps, float& xhat, float& rstd) {
     const float mean = group_sum<64>(v) * (1.0f / 64.0f);
@@ -138,6 +160,11 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     const int KH = (BF ? 8 : 4) * half;
     const int on = tid >> 2, osl = tid & 3;
     TSTAMP(1);
+    // kernarg fields in batches, a stage ahead of their use (see top_bwd_body)
+    float* const Pq = TP(q); float* const Pk = TP(k); float* const Pv = TP(v);
+    float* const k_low = TP(low); const DropP d_f = TP(drop_f); const float k_eps = TP(eps);
+    float* const k_xhat_f = TP(xhat_f); float* const k_rstd_f = TP(rstd_f);
+    const float* const pW1 = TP(w1); const float* const pW2 = TP(w2);
 
     // ---- K, V projections of all rows (MFMA), spectrum of x (VALU)
     {
@@ -156,11 +183,13 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     }
     auto xsrc = [&](int, int t, int lc) { return ld4(sX + t * FS + lc); };
     dft_spectrum_tab<1>(xsrc, L, cb, sTab, sSpec, sPart);        // ends with a barrier: sK / sV complete too
+#ifdef BSAREC_FINE_STAMPS
+    TSTAMP(10);
+#endif
 
     // q_last = x_last . Wq^T + bq  (4 lanes per output), and the k, v rows -> global (the backward reads them)
     {
         const float qv = gemv_rows_dot<64, 4>(R.wq4, sX + tl * FS, osl) + R.bq_n;
-        float* const Pq = TP(q); float* const Pk = TP(k); float* const Pv = TP(v);
         if (osl == 0) { sQ[on] = qv; ast<BF>(Pq, el + on, qv); }
         const int lr = tid >> 4, lc = (tid & 15) << 2;
         for (int r = lr; r < L; r += 16) {
@@ -168,22 +197,26 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
             ast4<BF>(Pv, (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
         }
     }
+#ifdef BSAREC_FINE_STAMPS
+    TSTAMP(11);
+#endif
     // FrequencyLayer output of the last row (wave 0, lane = column):  src/model/bsarec.py:90-104
     if (wave == 0) {
         const int c = lane, c4 = c & ~3;
         const f32x4 low4 = lowpass_tab(sSpec, tl, c4, L, cb, sTab);
         const float low = (c & 3) == 0 ? low4.x : (c & 3) == 1 ? low4.y : (c & 3) == 2 ? low4.z : low4.w;
         const float xv = sX[tl * FS + c];
-        gst(TP(low) + el + c, low);
+        gst(k_low + el + c, low);
         const float bt = R.c_beta;
         const float f = low + bt * bt * (xv - low);
-        const float v = f * drop_mult1(TP(drop_f), dseed, (uint64_t)(el + c)) + xv;
+        const float v = f * drop_mult1(d_f, dseed, (uint64_t)(el + c)) + xv;
         float xh, rs;
-        ln_row(v, TP(eps), xh, rs);
-        ast<BF>(TP(xhat_f), el + c, xh);
-        if (c == 0) gst(TP(rstd_f) + tok0 + tl, rs);
+        ln_row(v, k_eps, xh, rs);
+        ast<BF>(k_xhat_f, el + c, xh);
+        if (c == 0) gst(k_rstd_f + tok0 + tl, rs);
         sDsp[c] = R.c_fg * xh + R.c_fb;
     }
+    float* const k_probs = TP(probs); const DropP d_p = TP(drop_p); float* const k_ctx = TP(ctx);
     lds_barrier();
     TSTAMP(2);
     // feed-forward weight rows.  Lane n reads ITS row, 32-64 cache lines per wave instruction: the ISSUE of the 32 loads
@@ -191,7 +224,7 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     // are requested here; dense_2's (needed two steps later) by waves 1..3 while wave 0 runs the LayerNorm + mix row
     // alone, and by wave 0 right after it -- in the shadow of steps that leave the address path idle.
     f32x4 w1r[16], w2r[16];
-    gemv_rows_load<64, 1>(TP(w1), 64, tid, 0, w1r);
+    gemv_rows_load<64, 1>(pW1, 64, tid, 0, w1r);
 
     // ---- attention row of the last query: one wave per head, lane = key        src/model/_modules.py:118-135
     if (wave < heads) {
@@ -212,9 +245,11 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
         const float e = key < L ? __expf(s - mx) : 0.f;
         const float p = e / group_sum<64>(e);
         const long pe = (((long)b * heads + head) * L + tl) * Lp;
-        if (key < Lp) ast<BF>(TP(probs), pe + key, p);
-        sPd[head * 64 + key] = key < L ? p * drop_mult1(TP(drop_p), dseed, (uint64_t)(pe + key)) : 0.f;
+        if (key < Lp) ast<BF>(k_probs, pe + key, p);
+        sPd[head * 64 + key] = key < L ? p * drop_mult1(d_p, dseed, (uint64_t)(pe + key)) : 0.f;
     }
+    const DropP d_o = TP(drop_o); float* const k_xhat_a = TP(xhat_a); float* const k_rstd_a = TP(rstd_a);
+    const float k_alpha = TP(alpha), k_oma = TP(oma); float* const k_hmix = TP(hmix); float* const k_u = TP(u);
     lds_barrier();
     TSTAMP(3);
     if (tid < 64) {                               // ctx_last[c] = sum_j Drop(p)_j v_j[c]
@@ -225,7 +260,7 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
         for (int j = 0; j < 64; ++j) a4[j & 3] += sPd[head * 64 + j] * sV[j * FS + c];
         acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         sCtx[c] = acc;
-        ast<BF>(TP(ctx), el + c, acc);
+        ast<BF>(k_ctx, el + c, acc);
     }
     lds_barrier();
     TSTAMP(4);
@@ -237,27 +272,28 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     }
     lds_barrier();
     TSTAMP(5);
-    if (wave != 0) gemv_rows_load<256, 4>(TP(w2), 256, on, osl, w2r);
+    if (wave != 0) gemv_rows_load<256, 4>(pW2, 256, on, osl, w2r);
     if (wave == 0) {
         const int c = lane;
-        const float v = sG[c] * drop_mult1(TP(drop_o), dseed, (uint64_t)(el + c)) + sX[tl * FS + c];
+        const float v = sG[c] * drop_mult1(d_o, dseed, (uint64_t)(el + c)) + sX[tl * FS + c];
         float xh, rs;
-        ln_row(v, TP(eps), xh, rs);
-        ast<BF>(TP(xhat_a), el + c, xh);
-        if (c == 0) gst(TP(rstd_a) + tok0 + tl, rs);
+        ln_row(v, k_eps, xh, rs);
+        ast<BF>(k_xhat_a, el + c, xh);
+        if (c == 0) gst(k_rstd_a + tok0 + tl, rs);
         const float a = R.c_ag * xh + R.c_ab;
-        const float hm = TP(alpha) * sDsp[c] + TP(oma) * a;
+        const float hm = k_alpha * sDsp[c] + k_oma * a;
         sHm[c] = hm;
-        ast<BF>(TP(hmix), el + c, hm);
-        gemv_rows_load<256, 4>(TP(w2), 256, on, osl, w2r);
+        ast<BF>(k_hmix, el + c, hm);
+        gemv_rows_load<256, 4>(pW2, 256, on, osl, w2r);
     }
+    const DropP d_ff = TP(drop_ff); float* const k_xhat_ff = TP(xhat_ff); float* const k_rstd_ff = TP(rstd_ff); float* const k_Xout = TP(Xout);
     lds_barrier();
     TSTAMP(6);
 
     // ---- feed-forward (one row): u = hmix W1^T + b1 (one output per thread), y = gelu(u) W2^T + b2
     {
         const float u = gemv_rows_dot<64, 1>(w1r, sHm, 0) + R.b1_n;
-        ast<BF>(TP(u), (tok0 + tl) * 256 + tid, u);
+        ast<BF>(k_u, (tok0 + tl) * 256 + tid, u);
         sG[tid] = gelu_f(u);
     }
     lds_barrier();
@@ -270,12 +306,12 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     TSTAMP(8);
     if (wave == 0) {
         const int c = lane;
-        const float v = sQ[c] * drop_mult1(TP(drop_ff), dseed, (uint64_t)(el + c)) + sHm[c];
+        const float v = sQ[c] * drop_mult1(d_ff, dseed, (uint64_t)(el + c)) + sHm[c];
         float xh, rs;
-        ln_row(v, TP(eps), xh, rs);
-        ast<BF>(TP(xhat_ff), el + c, xh);
-        if (c == 0) gst(TP(rstd_ff) + tok0 + tl, rs);
-        gst(TP(Xout) + el + c, R.c_ffg * xh + R.c_ffb);           // the last layer's output is an fp32 tensor in every mode
+        ln_row(v, k_eps, xh, rs);
+        ast<BF>(k_xhat_ff, el + c, xh);
+        if (c == 0) gst(k_rstd_ff + tok0 + tl, rs);
+        gst(k_Xout + el + c, R.c_ffg * xh + R.c_ffb);           // the last layer's output is an fp32 tensor in every mode
     }
     TSTAMP(15);
 }
@@ -357,9 +393,155 @@ __device__ __forceinline__ float ln_row_bwd(float dy, float gamma, float xhat, f
 #define BSTAMP(i) do { long long* st_ = TB(stamps); if (st_ && blockIdx.x == 0 && threadIdx.x == 0) st_[i] = clock64(); } while (0)
 static_assert(TOP_BWD_BARRIERS == 11, "barriers of top_bwd_body (fused_layer.h holds the constant)");
 
+// What the chain that opens the top block's backward needs from memory (wave 0, one column per lane): requested at the
+// very top of the kernel so that the ~4 k cycles these loads take (the slabs were written by the previous kernel, on other
+// XCDs) pass under the twiddle-table build instead of in front of the first LayerNorm backward.
+template <bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_bwd_prefetch(TopBwdRegs& R) {          // wave 0 only
+    const int c = threadIdx.x & 63;
+    const int L = TB(L), b = blockIdx.x, tl = L - 1;
+    const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
+    // The slabs go through a buffer descriptor over exactly min(ns, 32) of them: one scalar offset per load instead of a
+    // 64-bit address, and a slab index >= ns is out of range and reads as 0 (no select) -- every instruction of wave 0 here is
+    // ~5 cycles of the step's critical path.
+    const int ns = TB(dh_nsplit);
+    const float* const slabs = TB(dh_slabs);
+    const long stride = TB(dh_stride);
+    const float* const k_xhat_ff = TB(xhat_ff); const float* const k_ff_g = TB(ff_g); const float* const k_rstd_ff = TB(rstd_ff);
+    const float* const k_xhat_a = TB(xhat_a); const float* const k_xhat_f = TB(xhat_f); const float* const k_a_g = TB(a_g);
+    const float* const k_f_g = TB(f_g); const float* const k_rstd_a = TB(rstd_a); const float* const k_rstd_f = TB(rstd_f);
+    const float* const k_beta = TB(sqrt_beta); const float* const k_low = TB(low); const float* const k_q = TB(q);
+    const float* const pX = TB(X);
+    const long slab_bytes = (long)min(ns, 32) * stride * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, (int)min(slab_bytes, 0x7fffffffL), 0x00020000);
+    const int voff = (b * 64 + c) * 4, sstep = (int)(stride * 4);
+#pragma unroll
+    for (int sp = 0; sp < 32; ++sp) R.sl[sp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, sp * sstep, 0));
+    R.xh_ff = ald<BF>(k_xhat_ff, el + c); R.g_ff = gld(k_ff_g + c); R.rs_ff = gld(k_rstd_ff + tok0 + tl);
+    R.xa = ald<BF>(k_xhat_a, el + c); R.xf = ald<BF>(k_xhat_f, el + c); R.g_a = gld(k_a_g + c); R.g_f = gld(k_f_g + c);
+    R.rs_a = gld(k_rstd_a + tok0 + tl); R.rs_f = gld(k_rstd_f + tok0 + tl);
+    R.bt = gld(k_beta + c); R.low_l = gld(k_low + el + c); R.x_l = ald<BF>(pX, el + c);
+    R.q_l = ald<BF>(k_q, el + c);
+    const int heads = TB(heads), Lp = TB(Lp);
+    R.p_pre = c < L ? ald<BF>(TB(probs), (((long)b * heads + 0) * L + tl) * Lp + c) : 0.f;
+}
+// waves 1..3 of the fused head: wave 1 the x tile, wave 2 k, wave 3 v (16 loads a lane; rows past L re-read row L-1 and are
+// zeroed at the store), and the probability row of head `wave` where there is one
+template <bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_bwd_prefetch_tile(TopBwdRegs& R) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = TB(L), Lp = TB(Lp), heads = TB(heads), b = blockIdx.x, tl = L - 1;
+    const long tok0 = (long)b * L;
+    const float* const src = wave == 1 ? TB(X) : wave == 2 ? TB(k) : TB(v);
+    R.p_pre = (wave < heads && lane < L) ? ald<BF>(TB(probs), (((long)b * heads + wave) * L + tl) * Lp + lane) : 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int idx = lane + p * 64, r = idx >> 4, c4 = (idx & 15) << 2;
+        R.tq[p] = ald4<BF>(src, (tok0 + min(r, L - 1)) * 64 + c4);
+    }
+}
+
+// per-head vectors of the attention backward (thread = (head, feature i)): the weight-gradient operands of key / value
+// (dWk = AK^T RK, dWv = AV^T RV), q_h Wk_h and dC_h Wv_h.  sVec offsets as in top_bwd_body.
 template <int DH, bool BF, unsigned KOFF>
-__device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, float* sK, float* sV, const float* sTab, float* sVec,
-                                             float* sDX) {
+__device__ __forceinline__ void top_bwd_head_vectors(int head, int i, int b, int heads, const float (&wkc)[DH], const float (&wvc)[DH],
+                                                     const float* sX, float* sVec) {
+    const float* sDC = sVec + 832; const float* sQ = sVec + 896; const float* sDs = sVec + 1024; const float* sPd = sVec + 1280;
+    float* sQK = sVec + 1536; float* sCV = sVec + 1792;
+    const int o = head * 64 + i;
+    float* const k_rk = TB(rk); float* const k_rv = TB(rv); float* const k_ak = TB(ak); float* const k_av = TB(av);
+    float rk = 0.f, rv = 0.f;
+    float rk2 = 0.f, rv2 = 0.f;
+#pragma unroll 16
+    for (int j = 0; j < 64; j += 2) {               // fixed trip count, two chains each
+        const float x0 = sX[j * FS + i], x1 = sX[(j + 1) * FS + i];
+        rk += sDs[head * 64 + j] * x0; rv += sPd[head * 64 + j] * x0;
+        rk2 += sDs[head * 64 + j + 1] * x1; rv2 += sPd[head * 64 + j + 1] * x1;
+    }
+    rk += rk2; rv += rv2;
+    const long e = ((long)b * heads + head) * 64 + i;
+    const bool mine = i / DH == head;
+    ast<BF>(k_rk, e, rk); ast<BF>(k_rv, e, rv);
+    ast<BF>(k_ak, e, mine ? sQ[i] : 0.f); ast<BF>(k_av, e, mine ? sDC[i] : 0.f);
+    sQK[o] = gemv_cols_dot<DH>(wkc, sQ, head * DH);
+    sCV[o] = gemv_cols_dot<DH>(wvc, sDC, head * DH);
+}
+
+// Waves 4..7 of fused_layer_bwd_kernel<.., TopBwdP> while waves 0..3 run top_bwd_body<.., HELPED = true>: they take the two
+// wide steps whose weight columns can be requested long before they are needed -- dU (64 dense_2 columns per thread), the
+// dH partials (64 dense_1 columns) and the per-head vectors -- so that neither the issue of those loads nor their registers sit on waves 0..3' dependent
+// chain.  help_a holds barriers 1-3 of TOP_BWD_BARRIERS, help_b barriers 4-11 (tests/test_host_cpu.py counts them); the
+// caller stages the lower block's gelu' tile between the two.
+template <bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_bwd_help_prefetch(TopBwdHelpRegs& H) {
+    const int t = (int)threadIdx.x - 256, lane = t & 63, hw = t >> 6;
+    const int L = TB(L), b = blockIdx.x;
+    const float* const pU = TB(u); const float* const pW2 = TB(w2); const float* const pW1 = TB(w1);
+    // wave hw: inner units [64 hw, 64 hw + 64) of dU (all 64 k of dense_2), and the same units as the K slice of dU . W1
+    H.u4 = ald4<BF>(pU, ((long)b * L + L - 1) * 256 + 64 * hw + 4 * (lane & 15));
+    gemv_cols4_load(pW2, 256, 0, 64 * hw, H.w2c);
+    gemv_cols4_load(pW1, 64, 64 * hw, 0, H.w1c);
+}
+template <bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_bwd_help_a(const TopBwdHelpRegs& H, float* sVec) {
+    const float* sDT = sVec; float* sDU = sVec + 64; float* sRed = sVec + 320;
+    const int t = (int)threadIdx.x - 256, lane = t & 63, hw = t >> 6;
+    const int b = blockIdx.x;
+    float* const k_dU = TB(dU);
+    const int g = lane & 15, kq = lane >> 4, u0 = 64 * hw + 4 * g;
+    const f32x4 u4 = H.u4;
+    const f32x4 (&w2c)[16] = H.w2c;
+    const f32x4 (&w1c)[16] = H.w1c;
+    lds_barrier();
+    // dU = (dT2 . W2) * gelu'(u)
+    const f32x4 s4 = gemv_cols4_dot(w2c, sDT, 0);
+    const f32x4 du = {s4.x * gelu_grad_f(u4.x), s4.y * gelu_grad_f(u4.y), s4.z * gelu_grad_f(u4.z), s4.w * gelu_grad_f(u4.w)};
+    if (kq == 0) { st4(sDU + u0, du); ast4<BF>(k_dU, (long)b * 256 + u0, du); }
+    lds_barrier();
+    // d(hmix) partials = dU . W1   (4 slices of 64 inner units; wave 0 of the body sums them)
+    const f32x4 h4 = gemv_cols4_dot(w1c, sDU, 64 * hw);
+    if (kq == 0) st4(sRed + hw * 64 + 4 * g, h4);
+    lds_barrier();
+}
+// gu / uw: the LOWER block's gelu' tile [L][256] -> registers, a quarter per barrier interval of the head's narrow steps.  A
+// wave that requests 16 KB at once sits in the issue of those loads until the memory pipeline has room (the whole head
+// moves ~240 KB through one CU's 64 B/clk path) and arrives late at the next barrier; nothing of the head needs this tile,
+// so it trickles in behind the loads the head does wait for.  The caller stores uw to LDS after the head.
+template <int DH, bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_bwd_help_b(const float* sX, float* sVec, const float* gu, f32x4 (&uw)[16]) {
+    const int t = (int)threadIdx.x - 256, lane = t & 63, hw = t >> 6;
+    const int heads = TB(heads), L = TB(L), b = blockIdx.x;
+    const long tok0 = (long)b * L;
+    const bool hv = hw < heads;
+    float wkc[DH], wvc[DH];
+    const float* const pWk = TB(wk); const float* const pWv = TB(wv);
+    auto u_quarter = [&](int q) {
+#pragma unroll
+        for (int i = 4 * q; i < 4 * q + 4; ++i) {
+            const int idx = t + i * 256, r = idx >> 6, c4 = (idx & 63) << 2;
+            uw[i] = ald4<BF>(gu, (tok0 + min(r, L - 1)) * 256 + c4);
+        }
+    };
+    gemv_cols_load<DH>(pWk, 64, (hv ? hw : 0) * DH, lane, wkc);
+    gemv_cols_load<DH>(pWv, 64, (hv ? hw : 0) * DH, lane, wvc);
+    lds_barrier();
+    u_quarter(0);                 // (steps 4, 5, 8, 9 of the body: the ones in which waves 0..3 touch no global memory)
+    lds_barrier();
+    u_quarter(1);
+    lds_barrier();
+    lds_barrier();
+    if (hv) top_bwd_head_vectors<DH, BF, KOFF>(hw, lane, b, heads, wkc, wvc, sX, sVec);
+    lds_barrier();
+    u_quarter(2);
+    lds_barrier();
+    u_quarter(3);
+    lds_barrier();
+    lds_barrier();
+}
+
+template <int DH, bool BF, unsigned KOFF, bool HELPED>
+__device__ __forceinline__ void top_bwd_body(const TopBwdRegs& R, const DropSeed& dseed, float* sX, float* sK, float* sV, const float* sTab,
+                                             float* sVec, float* sDX) {
     float* sDT = sVec;            // 64   dT2 (grad of the dense_2 output)
     float* sDU = sVec + 64;       // 256  dU
     float* sRed = sVec + 320;     // 256  partial sums [4][64]
@@ -383,97 +565,140 @@ __device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, f
     const int b = blockIdx.x, tl = L - 1;
     const long tok0 = (long)b * L, el = (tok0 + tl) * 64;
 
-    // Loads return in issue order (vmcnt), so the order of issue is the order of need: the row vectors of the
-    // LayerNorm steps first, then the dense_2 columns of the first product; the x / k / v tiles (needed from the
-    // attention step on) and the dense_1 columns are requested after the first barrier and land during dU / dH.
+    // The step opens with ONE dependent chain on wave 0 (upstream gradient -> LayerNorm backward -> dT2) that everything
+    // else waits for, so wave 0 issues that chain's loads before anything else and NO other load of its own until the chain
+    // is through (loads return in issue order, and the vmcnt field cannot name more than 63 younger loads); its three
+    // dropout multipliers of row L-1 (Philox, independent of the data) are evaluated under the latency of those loads.
+    // The other waves' bulk requests (dense_1 columns, the x / k / v tiles) are not waited for in this stage.
     const int c = lane;
-    // upstream gradient of the last row = sum of the logits backward's split-K slabs (<= 32): all loads issued back to
-    // back (a rolled loop would wait for every load before the next one: ~0.14 us of L2 latency per slab)
-    float dy = 0.f;
-    {
+    float dy = 0.f, dz_ff = 0.f;
+    float xa = 0.f, xf = 0.f, g_a = 0.f, g_f = 0.f, rs_a = 0.f, rs_f = 0.f, bt = 0.f, low_l = 0.f, x_l = 0.f;
+    float u_mine = 0.f;
+    float w2c[HELPED ? 1 : 64], w1c[HELPED ? 1 : 64];
+    f32x4 tx[4], tk[4], tv[4];
+    // kernarg fields are read in batches AHEAD of their use: kernarg_field is one scalar load, and a field read at its
+    // point of use costs that load's round trip (100-200 cycles) in front of every global access -- measured 5.4 k cycles for
+    // the 45 loads that open this step when each address was fetched on its own
+    const float* const pX = TB(X); const float* const pK = TB(k); const float* const pV = TB(v);
+    const float* const pW1 = TB(w1); const float* const pW2 = TB(w2); const float* const pU = TB(u);
+    const float* const pWo = TB(wo); const float* const pWq = TB(wq); const float* const pWk = TB(wk); const float* const pWv = TB(wv);
+    auto weight_loads = [&]() {                  // (HELPED: waves 4..7 hold these columns)
+        if constexpr (!HELPED) {
+            u_mine = ald<BF>(pU, (tok0 + tl) * 256 + tid);
+            gemv_cols_load<64>(pW2, 256, 0, tid, w2c);
+            gemv_cols_load<64>(pW1, 64, 64 * wave, lane, w1c);
+        }
+    };
+    auto tile_loads = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+            const long et = (tok0 + min(r, L - 1)) * 64 + c4;            // branch-free: rows past L re-read row L-1, zeroed
+            tx[p] = ald4<BF>(pX, et); tk[p] = ald4<BF>(pK, et); tv[p] = ald4<BF>(pV, et);
+            if (r >= L) { tx[p] = f32x4{0, 0, 0, 0}; tk[p] = tx[p]; tv[p] = tx[p]; }
+        }
+    };
+    if (wave != 0) {
+        if constexpr (!HELPED) { weight_loads(); tile_loads(); }
+        // the other two dropout multipliers of row L-1 (Philox, independent of the data): waves 1 and 2 have nothing else to do
+        // in this stage, wave 0 picks them up in the LayerNorm step (sDH / sDQ are free until then)
+        if (wave == 1) { const DropP d_o = TB(drop_o); sDH[c] = drop_mult1(d_o, dseed, (uint64_t)(el + c)); }
+        if (wave == 2) { const DropP d_f = TB(drop_f); sDQ[c] = drop_mult1(d_f, dseed, (uint64_t)(el + c)); }
+    }
+    if (wave == 0) {
+        // upstream gradient of the last row = sum of the logits backward's split-K slabs (requested by top_bwd_prefetch)
         const int ns = TB(dh_nsplit);
-        const float* const slabs = TB(dh_slabs);
-        const long stride = TB(dh_stride);
+        const DropP d_ff = TB(drop_ff);
+        float* const k_pg_ff = TB(pg_ff); float* const k_pb_ff = TB(pb_ff); float* const k_dT = TB(dT);
+        xa = R.xa; xf = R.xf; g_a = R.g_a; g_f = R.g_f; rs_a = R.rs_a; rs_f = R.rs_f; bt = R.bt; low_l = R.low_l; x_l = R.x_l;
+        const float m_ff = drop_mult1(d_ff, dseed, (uint64_t)(el + c));        // under what is left of the loads' latency
+        asm volatile("" :: "v"(m_ff));
+        __builtin_amdgcn_sched_barrier(0);
         float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sp = 0; sp < 32; ++sp) {
-            const float v = gld(slabs + (long)min(sp, ns - 1) * stride + (long)b * 64 + c);
-            part[sp & 3] += sp < ns ? v : 0.f;
+        for (int sp = 0; sp < 32; ++sp) part[sp & 3] += R.sl[sp];
+        if (ns > 32) {
+            const float* const slabs = TB(dh_slabs);
+            const long stride = TB(dh_stride);
+            for (int sp = 32; sp < ns; ++sp) part[0] += gld(slabs + (long)sp * stride + (long)b * 64 + c);
         }
-        for (int sp = 32; sp < ns; ++sp) part[0] += gld(slabs + (long)sp * stride + (long)b * 64 + c);
         dy = (part[0] + part[1]) + (part[2] + part[3]);
-    }
-    const float xh_ff = ald<BF>(TB(xhat_ff), el + c), g_ff = gld(TB(ff_g) + c), rs_ff = gld(TB(rstd_ff) + tok0 + tl);
-    const float xa = ald<BF>(TB(xhat_a), el + c), xf = ald<BF>(TB(xhat_f), el + c), g_a = gld(TB(a_g) + c), g_f = gld(TB(f_g) + c);
-    const float rs_a = gld(TB(rstd_a) + tok0 + tl), rs_f = gld(TB(rstd_f) + tok0 + tl);
-    const float bt = gld(TB(sqrt_beta) + c), low_l = gld(TB(low) + el + c), x_l = ald<BF>(TB(X), el + c);
-    const float u_mine = ald<BF>(TB(u), (tok0 + tl) * 256 + tid);
-    if (tid < 64) sQ[tid] = ald<BF>(TB(q), el + tid);
-    float w2c[64], w1c[64];
-    gemv_cols_load<64>(TB(w2), 256, 0, tid, w2c);
-    float dz_ff = 0.f;
-    if (wave == 0) {            // FeedForward LayerNorm backward (row L-1)
-        dz_ff = ln_row_bwd(dy, g_ff, xh_ff, rs_ff);
-        gst(TB(pg_ff) + (long)b * 64 + c, dy * xh_ff);
-        gst(TB(pb_ff) + (long)b * 64 + c, dy);
-        const float dt = dz_ff * drop_mult1(TB(drop_ff), dseed, (uint64_t)(el + c));
+        // FeedForward LayerNorm backward (row L-1)
+        dz_ff = ln_row_bwd(dy, R.g_ff, R.xh_ff, R.rs_ff);
+        const float dt = dz_ff * m_ff;
         sDT[c] = dt;
-        ast<BF>(TB(dT), (long)b * 64 + c, dt);
+        sQ[c] = R.q_l;
+        gst(k_pg_ff + (long)b * 64 + c, dy * R.xh_ff);
+        gst(k_pb_ff + (long)b * 64 + c, dy);
+        ast<BF>(k_dT, (long)b * 64 + c, dt);
+        if constexpr (!HELPED) { __builtin_amdgcn_sched_barrier(0); weight_loads(); tile_loads(); }
     }
+    // (stage 3's fields: read here, a stage ahead)
+    const float k_oma = TB(oma), k_alpha = TB(alpha);
+    float* const k_pg_a = TB(pg_a); float* const k_pb_a = TB(pb_a); float* const k_pg_f = TB(pg_f); float* const k_pb_f = TB(pb_f);
+    float* const k_dO = TB(dO); float* const k_pbeta = TB(pbeta); float* const k_dU = TB(dU);
     lds_barrier();
     BSTAMP(1);
-    gemv_cols_load<64>(TB(w1), 64, 64 * wave, lane, w1c);
-    f32x4 tx[4], tk[4], tv[4];
-    const float* const pX = TB(X); const float* const pK = TB(k); const float* const pV = TB(v);
+    // HELPED: the x / k / v tiles requested at the top of the kernel (top_bwd_prefetch_tile) have landed: -> LDS, while waves
+    // 4..7 run the next two steps
+    if constexpr (HELPED) {
+        if (wave != 0) {
+            float* const dst = wave == 1 ? sX : wave == 2 ? sK : sV;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
-        const long et = (tok0 + min(r, L - 1)) * 64 + c4;            // branch-free: rows past L re-read row L-1, zeroed
-        tx[p] = ald4<BF>(pX, et); tk[p] = ald4<BF>(pK, et); tv[p] = ald4<BF>(pV, et);
-        if (r >= L) { tx[p] = f32x4{0, 0, 0, 0}; tk[p] = tx[p]; tv[p] = tx[p]; }
+            for (int p = 0; p < 16; ++p) {
+                const int idx = lane + p * 64, r = idx >> 4, c4 = (idx & 15) << 2;
+                st4(dst + r * FS + c4, r < L ? R.tq[p] : f32x4{0, 0, 0, 0});
+            }
+        }
     }
 
-    // ---- dU = (dT2 . W2) * gelu'(u)   (one of the 256 inner units per thread)
-    {
+    // ---- dU = (dT2 . W2) * gelu'(u)   (one of the 256 inner units per thread; HELPED: waves 4..7 do it, top_bwd_help_a)
+    if constexpr (!HELPED) {
         const float du = gemv_cols_dot<64>(w2c, sDT, 0) * gelu_grad_f(u_mine);
         sDU[tid] = du;
-        ast<BF>(TB(dU), (long)b * 256 + tid, du);
+        ast<BF>(k_dU, (long)b * 256 + tid, du);
     }
+    float woc[16], wqc[16], wkc[HELPED ? 1 : DH], wvc[HELPED ? 1 : DH];
+    gemv_cols_load<16>(pWo, 64, 16 * wave, lane, woc);
+    gemv_cols_load<16>(pWq, 64, 16 * wave, lane, wqc);
+    const bool hv = tid < heads * 64;             // thread (head = wave, i = lane) of the per-head vector products
+    if constexpr (!HELPED) {
+        gemv_cols_load<DH>(pWk, 64, (hv ? wave : 0) * DH, lane, wkc);
+        gemv_cols_load<DH>(pWv, 64, (hv ? wave : 0) * DH, lane, wvc);
+    }
+    // (the attention step's and the per-head step's fields)
+    const float* const k_probs = TB(probs); const DropP d_p = TB(drop_p);
+    float* const k_dq = TB(dq); float* const k_pbk = TB(pbk); float* const k_pbv = TB(pbv);
     lds_barrier();
     BSTAMP(2);
-    // ---- d(hmix) = dU . W1 + dz   (4 slices of 64 inner units)
-    float woc[16], wqc[16], wkc[DH], wvc[DH];
-    gemv_cols_load<16>(TB(wo), 64, 16 * wave, lane, woc);
-    gemv_cols_load<16>(TB(wq), 64, 16 * wave, lane, wqc);
-    const bool hv = tid < heads * 64;             // thread (head = wave, i = lane) of the per-head vector products
-    gemv_cols_load<DH>(TB(wk), 64, (hv ? wave : 0) * DH, lane, wkc);
-    gemv_cols_load<DH>(TB(wv), 64, (hv ? wave : 0) * DH, lane, wvc);
-    sRed[wave * 64 + lane] = gemv_cols_dot<64>(w1c, sDU, 64 * wave);
+    // ---- d(hmix) = dU . W1 + dz   (4 slices of 64 inner units; HELPED: waves 4..7)
+    if constexpr (!HELPED) {
+        sRed[wave * 64 + lane] = gemv_cols_dot<64>(w1c, sDU, 64 * wave);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {                 // the tiles have landed by now
-        const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
-        st4(sX + r * FS + c4, tx[p]); st4(sK + r * FS + c4, tk[p]); st4(sV + r * FS + c4, tv[p]);
+        for (int p = 0; p < 4; ++p) {                 // the tiles have landed by now
+            const int idx = tid + p * 256, r = idx >> 4, c4 = (idx & 15) << 2;
+            st4(sX + r * FS + c4, tx[p]); st4(sK + r * FS + c4, tk[p]); st4(sV + r * FS + c4, tv[p]);
+        }
     }
     lds_barrier();
     BSTAMP(3);
     if (wave == 0) {
         const float dh = (sRed[c] + sRed[64 + c]) + (sRed[128 + c] + sRed[192 + c]) + dz_ff;
         // alpha mix + the two LayerNorm backwards (attention branch scaled by 1 - alpha, filter branch by alpha)
-        const float oma = TB(oma), alpha = TB(alpha);
-        const float dya = oma * dh, dyf = alpha * dh;
+        const float dya = k_oma * dh, dyf = k_alpha * dh;
         const float dza = ln_row_bwd(dya, g_a, xa, rs_a);
         const float dzf = ln_row_bwd(dyf, g_f, xf, rs_f);
-        gst(TB(pg_a) + (long)b * 64 + c, dya * xa); gst(TB(pb_a) + (long)b * 64 + c, dya);
-        gst(TB(pg_f) + (long)b * 64 + c, dyf * xf); gst(TB(pb_f) + (long)b * 64 + c, dyf);
-        const float dO = dza * drop_mult1(TB(drop_o), dseed, (uint64_t)(el + c));
-        const float dF = dzf * drop_mult1(TB(drop_f), dseed, (uint64_t)(el + c));
+        gst(k_pg_a + (long)b * 64 + c, dya * xa); gst(k_pb_a + (long)b * 64 + c, dya);
+        gst(k_pg_f + (long)b * 64 + c, dyf * xf); gst(k_pb_f + (long)b * 64 + c, dyf);
+        const float dO = dza * sDH[c];              // the multipliers waves 1 / 2 left there
+        const float dF = dzf * sDQ[c];
         sDO[c] = dO;
-        ast<BF>(TB(dO), (long)b * 64 + c, dO);
+        ast<BF>(k_dO, (long)b * 64 + c, dO);
         const float b2 = bt * bt;
         sDF[c] = (1.0f - b2) * dF;
         sLast[c] = dza + dzf + b2 * dF;
         // d sqrt_beta: f = low + beta^2 (x - low)
-        gst(TB(pbeta) + (long)b * 64 + c, 2.0f * bt * dF * (x_l - low_l));
+        gst(k_pbeta + (long)b * 64 + c, 2.0f * bt * dF * (x_l - low_l));
         // column L-1 of the low-pass projector: P[j][L-1] = (1/L) sum_k w_k cos(2 pi k (j - (L-1)) / L)
         float pl = 0.f;
         if (c < L)
@@ -482,6 +707,9 @@ __device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, f
                 pl += w * (sTab[2 * (k * 64 + c)] * sTab[2 * (k * 64 + tl)] + sTab[2 * (k * 64 + c) + 1] * sTab[2 * (k * 64 + tl) + 1]);
             }
         sPl[c] = pl / (float)L;
+#ifdef BSAREC_FINE_STAMPS
+        BSTAMP(12);
+#endif
     }
     lds_barrier();
     BSTAMP(4);
@@ -506,8 +734,8 @@ __device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, f
                 dpd += vv.x * dv.x + vv.y * dv.y + vv.z * dv.z + vv.w * dv.w;
             }
             const long pe = (((long)b * heads + head) * L + tl) * Lp + key;
-            p = ald<BF>(TB(probs), pe);
-            mp = drop_mult1(TB(drop_p), dseed, (uint64_t)pe);
+            p = HELPED ? R.p_pre : ald<BF>(k_probs, pe);
+            mp = drop_mult1(d_p, dseed, (uint64_t)pe);
         }
         const float dp = dpd * mp;
         const float delta = group_sum<64>(p * dp);
@@ -529,27 +757,12 @@ __device__ __forceinline__ void top_bwd_body(const DropSeed& dseed, float* sX, f
         for (int j = 0; j < 64; ++j) a4[j & 3] += sDs[head * 64 + j] * sK[j * FS + c];
         acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         sDQ[c] = acc;
-        ast<BF>(TB(dq), (long)b * 64 + c, acc);
-        gst(TB(pbk) + (long)b * 64 + c, sQ[c] * sSum[head]);
-        gst(TB(pbv) + (long)b * 64 + c, sDC[c] * sSum[4 + head]);
+        ast<BF>(k_dq, (long)b * 64 + c, acc);
+        gst(k_pbk + (long)b * 64 + c, sQ[c] * sSum[head]);
+        gst(k_pbv + (long)b * 64 + c, sDC[c] * sSum[4 + head]);
     }
-    if (hv) {
-        const int head = wave, i = lane, o = tid;
-        float rk = 0.f, rv = 0.f;
-        float rk2 = 0.f, rv2 = 0.f;
-#pragma unroll 16
-        for (int j = 0; j < 64; j += 2) {               // fixed trip count, two chains each
-            const float x0 = sX[j * FS + i], x1 = sX[(j + 1) * FS + i];
-            rk += sDs[head * 64 + j] * x0; rv += sPd[head * 64 + j] * x0;
-            rk2 += sDs[head * 64 + j + 1] * x1; rv2 += sPd[head * 64 + j + 1] * x1;
-        }
-        rk += rk2; rv += rv2;
-        const long e = ((long)b * heads + head) * 64 + i;
-        const bool mine = i / DH == head;
-        ast<BF>(TB(rk), e, rk); ast<BF>(TB(rv), e, rv);
-        ast<BF>(TB(ak), e, mine ? sQ[i] : 0.f); ast<BF>(TB(av), e, mine ? sDC[i] : 0.f);
-        sQK[o] = gemv_cols_dot<DH>(wkc, sQ, head * DH);
-        sCV[o] = gemv_cols_dot<DH>(wvc, sDC, head * DH);
+    if constexpr (!HELPED) {
+        if (hv) top_bwd_head_vectors<DH, BF, KOFF>(wave, lane, b, heads, wkc, wvc, sX, sVec);
     }
     lds_barrier();
     BSTAMP(8);
@@ -595,10 +808,12 @@ top_bwd_kernel(const TopBwdP P_unused) {
     float* sTab = sm + 3 * TS;                  // FUSED_MAX_CB * 128
     float* sVec = sTab + FUSED_MAX_CB * 128;
     BSTAMP(0);
+    TopBwdRegs R;
+    if (threadIdx.x < 64) top_bwd_prefetch<BF, KOFF>(R);
     const DropSeed dseed = drop_seed(TB(drop_f));
     build_twiddle_table(TB(tw), TB(L), TB(cb), sTab);
     lds_barrier();
-    top_bwd_body<DH, BF, KOFF>(dseed, sX, sK, sV, sTab, sVec, nullptr);
+    top_bwd_body<DH, BF, KOFF, false>(R, dseed, sX, sK, sV, sTab, sVec, nullptr);
 }
 
 

@@ -69,6 +69,12 @@ def test_top_bwd_body_barrier_count_matches_the_constant():
     assert len(lines) == const, (len(lines), const)
     assert all(re.match(r"^    lds_barrier\(\);", ln) for ln in lines), lines
     assert "return;" not in body
+    # the helper waves' two pieces (top_bwd_help_a / top_bwd_help_b) hold the same number between them
+    helper = top[top.index("void top_bwd_help_a("):top.index("void top_bwd_body(")]
+    hl = [ln for ln in helper.splitlines() if "lds_barrier();" in ln]
+    assert len(hl) == const, (len(hl), const)
+    assert all(re.match(r"^    lds_barrier\(\);", ln) for ln in hl), hl
+    assert "return;" not in helper
 
 
 def test_workspace_query_and_shape_limits():

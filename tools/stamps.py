@@ -23,7 +23,7 @@ for k in range(2):                      # the pruned top block (layer 1): raw st
     row = s[2 + k]
     n = 16
     vals = [int(v) for v in row[:n]]
-    nz = [i for i, v in enumerate(vals) if v]
+    nz = sorted((i for i, v in enumerate(vals) if v), key=lambda i: vals[i])
     print(f"layer 1 {'top_bwd' if k else 'top_fwd'} stamps:", " ".join(f"{i}:{vals[i] - vals[nz[0]]}" for i in nz))
 for l in range(1):
     for k in range(2):
@@ -32,3 +32,5 @@ for l in range(1):
             row[2] = row[1]              # the forward has no stamp between the FrequencyLayer || QKV phases
         d = np.diff(row[:9])
         print(f"layer {l} {'bwd' if k else 'fwd'} total {row[8]-row[0]} cyc:", " ".join(f"{n}={int(x)}" for n, x in zip(names[k], d)))
+print("bwd launch: kernel entry -> head start", int(s[3][0] - s[1][0]), " head", int(s[3][15] - s[3][0]), " head end -> stage A1 end", int(s[1][1] - s[3][15]))
+print("fwd launch: block end (stamp 8) -> tail start", int(s[2][1] - s[0][8]), " tail", int(s[2][15] - s[2][1]))
