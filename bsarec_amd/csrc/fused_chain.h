@@ -582,7 +582,7 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     // TAIL: the top block's weight fragments are requested here, in the shadow of the hand-over and the final row pass (lane n
     // reads ITS weight row: ~50 address-path cycles per wave instruction, the wave cannot move on before they are issued)
     TopFwdRegs<false> TR;
-    if constexpr (TAIL) { if (half == 0) top_fwd_prefetch<false, KOFF>(TR); }
+    if constexpr (TAIL) { if (half == 0) top_fwd_prefetch<false, KOFF, true>(TR); }
     if (half == 1) {
         if (tile_on) {
 #pragma unroll
@@ -622,7 +622,7 @@ fused_chain_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         for (int o = 0; o < 4; ++o) st4(sX + t * FS + 16 * o + 4 * g, y[o]);
         lds_barrier();                                               // ---- (waves 0..3 only: waves 4..7 have exited)
         STAMP(8);
-        top_fwd_rest<DH, false, KOFF>(TR, dseed, sX, sK, sVt, sRing, sTab, sSpec, sD, sIds);
+        top_fwd_rest<DH, false, KOFF, false>(TR, dseed, sX, sK, sVt, sRing, sTab, sSpec, sD, sIds);
     }
 #undef UNIT_BEGIN
 }

@@ -391,10 +391,14 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, cons
 // The one-row top block as the tail of this kernel (fused_top.h; declared here, defined there).
 struct NoTail {};
 template <bool BF> struct TopFwdRegs;
-template <bool BF, unsigned KOFF> __device__ __forceinline__ void top_fwd_prefetch(TopFwdRegs<BF>& R);
-template <int DH, bool BF, unsigned KOFF>
+template <bool BF, unsigned KOFF, bool KV> __device__ __forceinline__ void top_fwd_prefetch(TopFwdRegs<BF>& R);
+template <int DH, bool BF, unsigned KOFF, bool HELPED>
 __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const DropSeed& dseed, float* sX, float* sK, float* sV,
                                              float* sPart, float* sTab, float* sSpec, float* sVec, const int* sIds);
+template <bool BF> struct TopFwdHelpRegs;
+template <bool BF, unsigned KOFF> __device__ __forceinline__ void top_fwd_help_prefetch(TopFwdHelpRegs<BF>& H);
+template <int DH, bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_fwd_help(const TopFwdHelpRegs<BF>& H, const float* sX, float* sK, float* sV, float* sVec);
 template <class T> struct IsTail { static constexpr bool value = true; };
 template <> struct IsTail<NoTail> { static constexpr bool value = false; };
 // ... and its backward as the head of this block's backward kernel.  Waves 4..7 of that kernel execute exactly
@@ -927,7 +931,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     lds_barrier();
     STAMP(7);
     TopFwdRegs<BF> TR;
-    if constexpr (TAIL) { if (wave < 4) top_fwd_prefetch<BF, KOFF>(TR); }
+    TopFwdHelpRegs<BF> TH;
+    if constexpr (TAIL) { if (wave < 4) top_fwd_prefetch<BF, KOFF, false>(TR); else top_fwd_help_prefetch<BF, KOFF>(TH); }
     const auto R7_Xout = KARG(FusedFwdP, Xout);
     const auto R7_b2 = KARG(FusedFwdP, b2);
     const auto R7_drop_ff = KARG(FusedFwdP, drop_ff);
@@ -943,8 +948,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         // x tile of the top block = sD; K, V tiles and the DFT partials alias the dead feed-forward tile; row vectors alias
         // tile 0 (read by the row pass above until the barrier)
         lds_barrier();
-        if (wave >= 4) return;
-        top_fwd_rest<DH, BF, KOFF>(TR, dseed, sD, sR, sR + TS, sR + 2 * TS, sTab, sSpec, sX, sIds);
+        if (wave < 4) top_fwd_rest<DH, BF, KOFF, true>(TR, dseed, sD, sR, sR + TS, sR + 2 * TS, sTab, sSpec, sX, sIds);
+        else top_fwd_help<DH, BF, KOFF>(TH, sD, sR, sR + TS, sX);
     }
 }
 #undef PTYPE

@@ -124,7 +124,7 @@ struct TopFwdRegs {
     float c_beta, c_fg, c_fb, c_ag, c_ab, c_ffg, c_ffb;
 };
 
-template <bool BF, unsigned KOFF>
+template <bool BF, unsigned KOFF, bool KV>
 __device__ __forceinline__ void top_fwd_prefetch(TopFwdRegs<BF>& R) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -135,9 +135,11 @@ __device__ __forceinline__ void top_fwd_prefetch(TopFwdRegs<BF>& R) {
     const int wn = wave & 1, col = wn * 32 + l31;
     const int KH = (BF ? 8 : 4) * half;
     const long wrow = (long)col * 64 + KH;
-    load_w<BF, 64>(BF ? TP(wk_sh) : TP(wk), wrow, R.wA);
-    load_w<BF, 64>(BF ? TP(wv_sh) : TP(wv), wrow, R.wB);
-    R.bias_k = gld(TP(bk) + col); R.bias_v = gld(TP(bv) + col);
+    if constexpr (KV) {                    // (fused tail: waves 4..7 hold these, top_fwd_help_prefetch)
+        load_w<BF, 64>(BF ? TP(wk_sh) : TP(wk), wrow, R.wA);
+        load_w<BF, 64>(BF ? TP(wv_sh) : TP(wv), wrow, R.wB);
+        R.bias_k = gld(TP(bk) + col); R.bias_v = gld(TP(bv) + col);
+    }
     const int on = tid >> 2, osl = tid & 3;
     gemv_rows_load<64, 4>(TP(wq), 64, on, osl, R.wq4);
     gemv_rows_load<64, 4>(TP(wo), 64, on, osl, R.wo4);
@@ -146,11 +148,13 @@ __device__ __forceinline__ void top_fwd_prefetch(TopFwdRegs<BF>& R) {
 
 // sX: x tile (rows >= L zero), sIds, sTab filled by the caller; everything else is scratch of this function.
 // 256 threads (waves 0..3 of the workgroup; any other wave must have exited: the barriers count the live waves).
-template <int DH, bool BF, unsigned KOFF>
+template <int DH, bool BF, unsigned KOFF, bool HELPED>
 __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const DropSeed& dseed, float* sX, float* sK, float* sV,
                                              float* sPart, float* sTab, float* sSpec, float* sVec, const int* sIds) {
     float* sQ = sVec; float* sPd = sVec + 64; float* sCtx = sVec + 320; float* sHm = sVec + 384; float* sG = sVec + 448;
     float* sDsp = sVec + 704;
+    float* sMul = sVec + 768;                  // HELPED: [3][64] dropout multipliers of row L-1 (sites f, o, ff)
+    float* sMp = sVec + 960;                   // HELPED: [4][64] attention-dropout multipliers of the last query
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int L = TP(L), Lp = TP(Lp), heads = TP(heads), cb = TP(cb);
@@ -166,8 +170,8 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     float* const k_xhat_f = TP(xhat_f); float* const k_rstd_f = TP(rstd_f);
     const float* const pW1 = TP(w1); const float* const pW2 = TP(w2);
 
-    // ---- K, V projections of all rows (MFMA), spectrum of x (VALU)
-    {
+    // ---- K, V projections of all rows (MFMA; HELPED: by waves 4..7, top_fwd_help), spectrum of x (VALU)
+    if constexpr (!HELPED) {
         const int arow = (wm * 32 + l31) * FS + KH;
         f32x16 acc;
 #pragma unroll
@@ -181,8 +185,32 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
 #pragma unroll
         for (int r = 0; r < 16; ++r) sV[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + R.bias_v;
     }
-    auto xsrc = [&](int, int t, int lc) { return ld4(sX + t * FS + lc); };
-    dft_spectrum_tab<1>(xsrc, L, cb, sTab, sSpec, sPart);        // ends with a barrier: sK / sV complete too
+#ifdef BSAREC_FINE_STAMPS
+    TSTAMP(9);
+#endif
+    if constexpr (!HELPED) {
+        auto xsrc = [&](int, int t, int lc) { return ld4(sX + t * FS + lc); };
+        dft_spectrum_tab<1>(xsrc, L, cb, sTab, sSpec, sPart);        // ends with a barrier: sK / sV complete too
+    } else {
+        // Only the low-pass component of row L-1 is needed, and that is one projector row applied to the x tile:
+        //   low[L-1][c] = sum_t P[t] x[t][c],  P[t] = (1/L) sum_k w_k cos(2 pi k (t - (L-1)) / L)   (w_0 = w_{L/2} = 1, else 2)
+        // (the spectrum + synthesis of dft_spectrum_tab / lowpass_tab, contracted over the bins first).  Wave w takes rows
+        // [16 w, 16 w + 16): lanes 0..15 evaluate P, each lane = one column sums its 16 rows with P read lane by lane.
+        if (wave == 1) sMul[lane] = drop_mult1(d_f, dseed, (uint64_t)(el + lane));      // wave 0 needs this one first
+        const int t = 16 * wave + (lane & 15);
+        float pl = 0.f;
+        if (t < L)
+            for (int k = 0; k < cb; ++k) {
+                const float w = (k == 0 || 2 * k == L) ? 1.0f : 2.0f;
+                pl += w * (sTab[2 * (k * 64 + t)] * sTab[2 * (k * 64 + tl)] + sTab[2 * (k * 64 + t) + 1] * sTab[2 * (k * 64 + tl) + 1]);
+            }
+        pl *= 1.0f / (float)L;
+        float a2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            a2[j & 1] += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pl), j)) * sX[(16 * wave + j) * FS + lane];
+        sPart[wave * 64 + lane] = a2[0] + a2[1];
+    }
 #ifdef BSAREC_FINE_STAMPS
     TSTAMP(10);
 #endif
@@ -191,30 +219,50 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     {
         const float qv = gemv_rows_dot<64, 4>(R.wq4, sX + tl * FS, osl) + R.bq_n;
         if (osl == 0) { sQ[on] = qv; ast<BF>(Pq, el + on, qv); }
-        const int lr = tid >> 4, lc = (tid & 15) << 2;
-        for (int r = lr; r < L; r += 16) {
-            ast4<BF>(Pk, (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
-            ast4<BF>(Pv, (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
+        if constexpr (!HELPED) {
+            const int lr = tid >> 4, lc = (tid & 15) << 2;
+            for (int r = lr; r < L; r += 16) {
+                ast4<BF>(Pk, (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
+                ast4<BF>(Pv, (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
+            }
         }
     }
+    if constexpr (HELPED) lds_barrier();           // (the partial sums; waves 4..7: after their V projection)
 #ifdef BSAREC_FINE_STAMPS
     TSTAMP(11);
 #endif
     // FrequencyLayer output of the last row (wave 0, lane = column):  src/model/bsarec.py:90-104
     if (wave == 0) {
         const int c = lane, c4 = c & ~3;
-        const f32x4 low4 = lowpass_tab(sSpec, tl, c4, L, cb, sTab);
-        const float low = (c & 3) == 0 ? low4.x : (c & 3) == 1 ? low4.y : (c & 3) == 2 ? low4.z : low4.w;
+        float low;
+        if constexpr (HELPED) low = (sPart[c] + sPart[64 + c]) + (sPart[128 + c] + sPart[192 + c]);
+        else {
+            const f32x4 low4 = lowpass_tab(sSpec, tl, c4, L, cb, sTab);
+            low = (c & 3) == 0 ? low4.x : (c & 3) == 1 ? low4.y : (c & 3) == 2 ? low4.z : low4.w;
+        }
         const float xv = sX[tl * FS + c];
         gst(k_low + el + c, low);
         const float bt = R.c_beta;
         const float f = low + bt * bt * (xv - low);
-        const float v = f * drop_mult1(d_f, dseed, (uint64_t)(el + c)) + xv;
+        const float v = f * (HELPED ? sMul[c] : drop_mult1(d_f, dseed, (uint64_t)(el + c))) + xv;
         float xh, rs;
         ln_row(v, k_eps, xh, rs);
         ast<BF>(k_xhat_f, el + c, xh);
         if (c == 0) gst(k_rstd_f + tok0 + tl, rs);
         sDsp[c] = R.c_fg * xh + R.c_fb;
+    }
+    if constexpr (HELPED) {
+        // the other dropout masks of the one-row chain, on the waves that have nothing else to do in this step: wave 2 the
+        // dense output's and the attention rows of heads 0, 2; wave 3 the feed-forward output's and heads 1, 3
+        if (wave >= 2) {
+            const DropP dd = wave == 2 ? TP(drop_o) : TP(drop_ff);
+            sMul[(wave - 1) * 64 + lane] = drop_mult1(dd, dseed, (uint64_t)(el + lane));
+            const DropP dp = TP(drop_p);
+            for (int h = wave - 2; h < heads; h += 2) {
+                const long pe = (((long)b * heads + h) * L + tl) * Lp;
+                sMp[h * 64 + lane] = drop_mult1(dp, dseed, (uint64_t)(pe + lane));
+            }
+        }
     }
     float* const k_probs = TP(probs); const DropP d_p = TP(drop_p); float* const k_ctx = TP(ctx);
     lds_barrier();
@@ -223,8 +271,8 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     // costs ~7 k cycles of the CU's address path and the wave cannot move on before its loads are issued.  dense_1's rows
     // are requested here; dense_2's (needed two steps later) by waves 1..3 while wave 0 runs the LayerNorm + mix row
     // alone, and by wave 0 right after it -- in the shadow of steps that leave the address path idle.
-    f32x4 w1r[16], w2r[16];
-    gemv_rows_load<64, 1>(pW1, 64, tid, 0, w1r);
+    f32x4 w1r[HELPED ? 1 : 16], w2r[HELPED ? 1 : 16];
+    if constexpr (!HELPED) gemv_rows_load<64, 1>(pW1, 64, tid, 0, w1r);
 
     // ---- attention row of the last query: one wave per head, lane = key        src/model/_modules.py:118-135
     if (wave < heads) {
@@ -246,7 +294,7 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
         const float p = e / group_sum<64>(e);
         const long pe = (((long)b * heads + head) * L + tl) * Lp;
         if (key < Lp) ast<BF>(k_probs, pe + key, p);
-        sPd[head * 64 + key] = key < L ? p * drop_mult1(d_p, dseed, (uint64_t)(pe + key)) : 0.f;
+        sPd[head * 64 + key] = key < L ? p * (HELPED ? sMp[head * 64 + key] : drop_mult1(d_p, dseed, (uint64_t)(pe + key))) : 0.f;
     }
     const DropP d_o = TP(drop_o); float* const k_xhat_a = TP(xhat_a); float* const k_rstd_a = TP(rstd_a);
     const float k_alpha = TP(alpha), k_oma = TP(oma); float* const k_hmix = TP(hmix); float* const k_u = TP(u);
@@ -272,10 +320,10 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     }
     lds_barrier();
     TSTAMP(5);
-    if (wave != 0) gemv_rows_load<256, 4>(pW2, 256, on, osl, w2r);
+    if constexpr (!HELPED) { if (wave != 0) gemv_rows_load<256, 4>(pW2, 256, on, osl, w2r); }
     if (wave == 0) {
         const int c = lane;
-        const float v = sG[c] * drop_mult1(d_o, dseed, (uint64_t)(el + c)) + sX[tl * FS + c];
+        const float v = sG[c] * (HELPED ? sMul[64 + c] : drop_mult1(d_o, dseed, (uint64_t)(el + c))) + sX[tl * FS + c];
         float xh, rs;
         ln_row(v, k_eps, xh, rs);
         ast<BF>(k_xhat_a, el + c, xh);
@@ -284,21 +332,21 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
         const float hm = k_alpha * sDsp[c] + k_oma * a;
         sHm[c] = hm;
         ast<BF>(k_hmix, el + c, hm);
-        gemv_rows_load<256, 4>(pW2, 256, on, osl, w2r);
+        if constexpr (!HELPED) gemv_rows_load<256, 4>(pW2, 256, on, osl, w2r);
     }
     const DropP d_ff = TP(drop_ff); float* const k_xhat_ff = TP(xhat_ff); float* const k_rstd_ff = TP(rstd_ff); float* const k_Xout = TP(Xout);
     lds_barrier();
     TSTAMP(6);
 
-    // ---- feed-forward (one row): u = hmix W1^T + b1 (one output per thread), y = gelu(u) W2^T + b2
-    {
+    // ---- feed-forward (one row): u = hmix W1^T + b1 (one output per thread), y = gelu(u) W2^T + b2   (HELPED: waves 4..7)
+    if constexpr (!HELPED) {
         const float u = gemv_rows_dot<64, 1>(w1r, sHm, 0) + R.b1_n;
         ast<BF>(k_u, (tok0 + tl) * 256 + tid, u);
         sG[tid] = gelu_f(u);
     }
     lds_barrier();
     TSTAMP(7);
-    {
+    if constexpr (!HELPED) {
         const float y = gemv_rows_dot<256, 4>(w2r, sG, osl) + R.b2_n;
         if (osl == 0) sQ[on] = y;
     }
@@ -306,7 +354,7 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
     TSTAMP(8);
     if (wave == 0) {
         const int c = lane;
-        const float v = sQ[c] * drop_mult1(d_ff, dseed, (uint64_t)(el + c)) + sHm[c];
+        const float v = sQ[c] * (HELPED ? sMul[128 + c] : drop_mult1(d_ff, dseed, (uint64_t)(el + c))) + sHm[c];
         float xh, rs;
         ln_row(v, k_eps, xh, rs);
         ast<BF>(k_xhat_ff, el + c, xh);
@@ -314,6 +362,122 @@ __device__ __forceinline__ void top_fwd_rest(const TopFwdRegs<BF>& R, const Drop
         gst(k_Xout + el + c, R.c_ffg * xh + R.c_ffb);           // the last layer's output is an fp32 tensor in every mode
     }
     TSTAMP(15);
+}
+
+// Waves 4..7 of fused_layer_fwd_kernel<.., TopFwdP> while waves 0..3 run top_fwd_rest<.., HELPED = true>.  They take
+//   * the K and V projections of all rows (MFMA; 2 x 2 waves tile 64 tokens x 64 features), and the copy of the finished
+//     tiles to global memory,
+//   * the one-row feed-forward: dense_1 / dense_2 rows read as WHOLE rows (one wave instruction = 1 KB contiguous; a lane per
+//     row costs 64 cache lines an instruction and ~7 k cycles of the CU's address path), requested four loads at a time
+//     in the steps in between, each product reduced across lanes.
+// Their barriers mirror top_fwd_rest<.., HELPED = true>'s one for one (eight).
+template <bool BF>
+struct TopFwdHelpRegs {
+    WFrag<BF, 64> wA, wB;                  // K / V weight fragments of this wave's 32 x 32 tile
+    float bias_k, bias_v;
+};
+template <bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_fwd_help_prefetch(TopFwdHelpRegs<BF>& H) {
+    const int lane = threadIdx.x & 63, hw = ((int)threadIdx.x >> 6) - 4;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wn = hw & 1, col = wn * 32 + l31;
+    const int KH = (BF ? 8 : 4) * half;
+    load_w<BF, 64>(BF ? TP(wv_sh) : TP(wv), (long)col * 64 + KH, H.wB);
+    load_w<BF, 64>(BF ? TP(wk_sh) : TP(wk), (long)col * 64 + KH, H.wA);
+    H.bias_v = gld(TP(bv) + col); H.bias_k = gld(TP(bk) + col);
+}
+template <int DH, bool BF, unsigned KOFF>
+__device__ __forceinline__ void top_fwd_help(const TopFwdHelpRegs<BF>& H, const float* sX, float* sK, float* sV, float* sVec) {
+    float* sQ = sVec; const float* sHm = sVec + 384; float* sG = sVec + 448;
+    const int t = (int)threadIdx.x - 256, lane = t & 63, hw = t >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int L = TP(L);
+    const int b = blockIdx.x, tl = L - 1;
+    const long tok0 = (long)b * L;
+    const int wm = hw >> 1, wn = hw & 1, col = wn * 32 + l31;
+    const int KH = (BF ? 8 : 4) * half;
+    const float* const pW1 = TP(w1); const float* const pW2 = TP(w2);
+    float* const Pk = TP(k); float* const Pv = TP(v); float* const k_u = TP(u);
+    // ---- V, then K projection of all rows -- the 64 fp32 MFMAs occupy the SIMD's vector ALU for ~4.2 k cycles wherever they
+    //      run; on THESE waves they run beside the other group's FrequencyLayer / query / LayerNorm row instead of ahead of it
+    const int arow = (wm * 32 + l31) * FS + KH;
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_w<BF, 64>(sX + arow, H.wB, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sV[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + H.bias_v;
+    }
+    lds_barrier();                                               // (the low-pass partial sums of the other group)
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        mma_w<BF, 64>(sX + arow, H.wA, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sK[(wm * 32 + rho(r) + 4 * half) * FS + col] = acc[r] + H.bias_k;
+    }
+    lds_barrier();                                               // K, V complete: the attention row starts
+    // K, V tiles -> global (the backward reads them)
+    {
+        const int lr = t >> 4, lc = (t & 15) << 2;
+        for (int r = lr; r < L; r += 16) {
+            ast4<BF>(Pk, (tok0 + r) * 64 + lc, ld4(sK + r * FS + lc));
+            ast4<BF>(Pv, (tok0 + r) * 64 + lc, ld4(sV + r * FS + lc));
+        }
+    }
+    // dense_1: wave hw owns units [64 hw, 64 hw + 64); load p = rows 4 p .. 4 p + 3 of them (lane l: row 4 p + (l >> 4), columns
+    // 4 (l & 15) ..); dense_2: outputs [16 hw, 16 hw + 16), load p = row p whole (lane l: inner units 4 l ..)
+    f32x4 w1r[16], w2r[16];
+    const float* const w1p = pW1 + (long)(64 * hw) * 64 + 4 * lane;
+    const float* const w2p = pW2 + (long)(16 * hw) * 256 + 4 * lane;
+    auto w1_quarter = [&](int q) {
+#pragma unroll
+        for (int p = 4 * q; p < 4 * q + 4; ++p) w1r[p] = gld4(w1p + p * 256);
+    };
+    auto w2_quarter = [&](int q) {
+#pragma unroll
+        for (int p = 4 * q; p < 4 * q + 4; ++p) w2r[p] = gld4(w2p + p * 256);
+    };
+    const int my_unit = 64 * hw + 4 * (lane & 15) + (lane >> 4);       // the unit whose sum lane l keeps (p = l & 15)
+    const float b1_n = gld(TP(b1) + my_unit);
+    const float b2_n = gld(TP(b2) + 16 * hw + (lane & 15));
+    w1_quarter(0); w1_quarter(1);
+    lds_barrier();
+    w1_quarter(2); w1_quarter(3);
+    lds_barrier();
+    w2_quarter(0);
+    lds_barrier();
+    w2_quarter(1); w2_quarter(2);
+    lds_barrier();
+    // ---- u = hmix W1^T + b1, gelu
+    {
+        const f32x4 hm = ld4(sHm + 4 * (lane & 15));
+        float mine = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float part = group_sum<16>(w1r[p].x * hm.x + w1r[p].y * hm.y + w1r[p].z * hm.z + w1r[p].w * hm.w);
+            mine = (lane & 15) == p ? part : mine;
+        }
+        const float u = mine + b1_n;
+        ast<BF>(k_u, (tok0 + tl) * 256 + my_unit, u);
+        sG[my_unit] = gelu_f(u);
+    }
+    w2_quarter(3);
+    lds_barrier();
+    // ---- y = gelu(u) W2^T + b2
+    {
+        const f32x4 g4 = ld4(sG + 4 * lane);
+        float mine = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float part = group_sum<64>(w2r[p].x * g4.x + w2r[p].y * g4.y + w2r[p].z * g4.z + w2r[p].w * g4.w);
+            mine = (lane & 15) == p ? part : mine;
+        }
+        if (lane < 16) sQ[16 * hw + lane] = mine + b2_n;
+    }
+    lds_barrier();
 }
 
 template <int DH, bool BF>
@@ -336,7 +500,7 @@ top_fwd_kernel(const TopFwdP P_unused) {
     const long tok0 = (long)blockIdx.x * L;
     const DropSeed dseed = drop_seed(TP(drop_f));
     TopFwdRegs<BF> R;
-    top_fwd_prefetch<BF, KOFF>(R);
+    top_fwd_prefetch<BF, KOFF, true>(R);
     {
         const float* const X = TP(X);
 #pragma unroll
@@ -350,7 +514,7 @@ top_fwd_kernel(const TopFwdP P_unused) {
     if (tid < 64) sIds[tid] = tid < L ? gldi(TP(ids32) + (tok0 + tid)) : 0;
     build_twiddle_table(TP(tw), L, cb, sTab);
     lds_barrier();
-    top_fwd_rest<DH, BF, KOFF>(R, dseed, sX, sK, sV, sPart, sTab, sSpec, sVec, sIds);
+    top_fwd_rest<DH, BF, KOFF, false>(R, dseed, sX, sK, sV, sPart, sTab, sSpec, sVec, sIds);
 }
 
 static inline size_t top_fwd_smem_bytes() { return (size_t)(3 * 64 * FS + 8192 + 2 * FUSED_MAX_CB * 128 + 768 + 64) * 4; }
