@@ -482,7 +482,9 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     float* const trash = KARG(FusedFwdP, trash) + 4 * lane;
 
     STAMP(0);
+    const KernargTouch ktouch = kernarg_touch<IsTail<TAILP>::value ? KOFF + (unsigned)sizeof(TAILP) : (unsigned)sizeof(FusedFwdP)>();
     const DropSeed dseed = drop_seed(KARG(FusedFwdP, drop_f));     // first loads of the kernel
+    kernarg_touch_done(ktouch);
     const auto R1_X = KARG(FusedFwdP, X);
     const auto R1_ids32 = KARG(FusedFwdP, ids32);
     const auto R1_tw = KARG(FusedFwdP, tw);
@@ -505,13 +507,16 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
         const float* const epos = KARG(FusedFwdP, e_pos);
         const int V = KARG(FusedFwdP, e_V);
         const float eeps = KARG(FusedFwdP, eps);
+        const float* const e_g = KARG(FusedFwdP, e_g); const float* const e_b = KARG(FusedFwdP, e_b);
+        int* const e_ids32 = KARG(FusedFwdP, e_ids32); const DropP e_drop = KARG(FusedFwdP, e_drop);
+        float* const e_xhat = KARG(FusedFwdP, e_xhat); float* const e_X0 = KARG(FusedFwdP, e_X0); float* const e_rstd = KARG(FusedFwdP, e_rstd);
         long src = 0;
         if (gp.table) {
             src = *(const AS_GLOBAL long long*)gp.cursor + b;
             src = src < gp.n ? (long)*(const AS_GLOBAL int64_t*)(gp.perm + src) : 0;
             if (tid == 0) *(AS_GLOBAL int64_t*)(gp.ans_out + b) = *(const AS_GLOBAL int64_t*)(gp.ans_table + src);
         }
-        const f32x4 eg = gld4(KARG(FusedFwdP, e_g) + ((tid & 15) << 2)), eb = gld4(KARG(FusedFwdP, e_b) + ((tid & 15) << 2));
+        const f32x4 eg = gld4(e_g + ((tid & 15) << 2)), eb = gld4(e_b + ((tid & 15) << 2));
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int idx = tid + p * 512, r = idx >> 4, c4 = (idx & 15) << 2;
@@ -529,7 +534,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
                 id = id < 0 ? 0 : (id >= V ? V - 1 : id);     // defensive clamp: never read outside the table
                 v = gld4(eE + (long)id * 64 + c4) + gld4(epos + (long)r * 64 + c4);
             }
-            if (c4 == 0) { sIds[r] = id; if (ok) *(AS_GLOBAL int*)(KARG(FusedFwdP, e_ids32) + tok0 + r) = id; }
+            if (c4 == 0) { sIds[r] = id; if (ok) *(AS_GLOBAL int*)(e_ids32 + tok0 + r) = id; }
             const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
             f32x4 dl = {0, 0, 0, 0};
             if (ok) dl = v - mean;
@@ -538,10 +543,10 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
             f32x4 y = {0, 0, 0, 0};
             if (ok) {
                 const f32x4 xh = dl * rs;
-                y = (eg * xh + eb) * drop_mult4(KARG(FusedFwdP, e_drop), dseed, (uint64_t)e >> 2);
-                ast4<BF>(KARG(FusedFwdP, e_xhat), e, xh);
-                ast4<BF>(KARG(FusedFwdP, e_X0), e, y);
-                if (c4 == 0) gst(KARG(FusedFwdP, e_rstd) + tok0 + r, rs);
+                y = (eg * xh + eb) * drop_mult4(e_drop, dseed, (uint64_t)e >> 2);
+                ast4<BF>(e_xhat, e, xh);
+                ast4<BF>(e_X0, e, y);
+                if (c4 == 0) gst(e_rstd + tok0 + r, rs);
             }
             st4(sX + r * FS + c4, y);
         }
