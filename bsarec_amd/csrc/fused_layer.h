@@ -345,27 +345,37 @@ __device__ __forceinline__ void mma_ll(const float* __restrict__ sa, const float
     }
 }
 
-// LayerNorm row pass over a 64 x 64 LDS tile held as two split-K partial tiles (16 lanes x float4 per row,
-// blockDim/16 rows per pass):  v = (tileA + tileB + bias) * dropout + residual ; xhat, rstd -> global ;
+// LayerNorm row pass over a 64 x 64 LDS tile held as two split-K partial tiles (16 lanes x float4 per row, 512 threads = 32
+// rows per pass, two passes):  v = (tileA + tileB + bias) * dropout + residual ; xhat, rstd -> global ;
 // y = gamma*xhat + beta ; MIX: y = alpha*dsp + (1-alpha)*y.  Result -> LDS (outL, may be null) and global (outG).
+// In two pieces: ln_pre requests the three per-column vectors and evaluates the thread's two dropout masks (Philox) -- neither
+// depends on the tile, so the caller places it BEFORE the matrix product that fills the tile and ahead of any weight
+// prefetch (loads return in issue order: a 16-byte vector requested behind 64 KB of weights waits for all of them).
+struct LnPre { f32x4 bi, g, be, dm[2]; };
+__device__ __forceinline__ LnPre ln_pre(const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const DropP& drop, const DropSeed& dseed, long tok0) {
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
+    LnPre P;
+    P.bi = gld4(bias + lc); P.g = gld4(gamma + lc); P.be = gld4(beta + lc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) P.dm[i] = drop_mult4(drop, dseed, (uint64_t)((tok0 + lr + 32 * i) * 64 + lc) >> 2);
+    return P;
+}
 template <bool MIX, bool BF>
-__device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, const float* __restrict__ tileB,
-                                           const float* __restrict__ bias, const float* __restrict__ resid,
-                                           const DropP& drop, const DropSeed& dseed, const float* __restrict__ gamma,
-                                           const float* __restrict__ beta, float eps, const float* __restrict__ dsp,
+__device__ __forceinline__ void ln_rows_64(const LnPre& P, const float* __restrict__ tileA, const float* __restrict__ tileB,
+                                           const float* __restrict__ resid, float eps, const float* __restrict__ dsp,
                                            float alpha, float oma, long tok0, int L, float* __restrict__ outL,
                                            float* __restrict__ outG, float* __restrict__ xhatG, float* __restrict__ rstdG,
                                            bool out_f32 = false /* BF: outG is an fp32 tensor (the last layer's output) */,
                                            bool round_outL = false /* BF: the LDS copy holds what a reader of outG would see */) {
     const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) << 2;
-    const int rpp = blockDim.x >> 4;
-    const f32x4 bi = gld4(bias + lc), g = gld4(gamma + lc), be = gld4(beta + lc);
-    for (int r = lr; r < 64; r += rpp) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = lr + 32 * i;
         const bool ok = r < L;
         const long e = (tok0 + r) * 64 + lc;
         f32x4 v = {0, 0, 0, 0};
-        if (ok) v = (ld4(tileA + r * FS + lc) + ld4(tileB + r * FS + lc) + bi) * drop_mult4(drop, dseed, (uint64_t)e >> 2) +
-                    ld4(resid + r * FS + lc);
+        if (ok) v = (ld4(tileA + r * FS + lc) + ld4(tileB + r * FS + lc) + P.bi) * P.dm[i] + ld4(resid + r * FS + lc);
         const float mean = group_sum<16>(v.x + v.y + v.z + v.w) * (1.0f / 64.0f);
         f32x4 dl = {0, 0, 0, 0};
         if (ok) dl = v - mean;
@@ -374,7 +384,7 @@ __device__ __forceinline__ void ln_rows_64(const float* __restrict__ tileA, cons
         f32x4 y = {0, 0, 0, 0};
         if (ok) {
             const f32x4 xh = dl * rs;
-            y = g * xh + be;
+            y = P.g * xh + P.be;
             if (MIX) y = alpha * ld4(dsp + r * FS + lc) + oma * y;
             ast4<BF>(xhatG, e, xh);
             if (BF && out_f32) gst4(outG + e, y); else ast4<BF>(outG, e, y);
@@ -855,6 +865,8 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     const auto R4_xhat_a = KARG(FusedFwdP, xhat_a);
     float ffn_bias[2];
     // ---- phase 4: dense (K split across the groups) + dropout + residual + LayerNorm + alpha mix
+    LnPre lnA;
+    if constexpr (!FM) lnA = ln_pre(R4_bo, R4_a_g, R4_a_b, R4_drop_o, dseed, tok0);
     {
         load_w<MM, 64>(R4_w1, (long)(128 * grp + col) * 64 + KH, wA);      // first dense_1 block of this group
         ffn_bias[0] = gld(KARG(FusedFwdP, b1) + 128 * grp + col); ffn_bias[1] = gld(KARG(FusedFwdP, b1) + 128 * grp + 64 + col);
@@ -870,8 +882,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     }
     if constexpr (!FM) {
     lds_barrier();
-    ln_rows_64<true, BF>(sQ, sK, R4_bo, sX, R4_drop_o, dseed, R4_a_g, R4_a_b, R4_eps, sD, R4_alpha, R4_oma, tok0, L, sH, R4_hmix, R4_xhat_a,
-                     R4_rstd_a);
+    ln_rows_64<true, BF>(lnA, sQ, sK, sX, R4_eps, sD, R4_alpha, R4_oma, tok0, L, sH, R4_hmix, R4_xhat_a, R4_rstd_a);
     lds_barrier();
     }
 
@@ -908,6 +919,11 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     const auto R6_w2 = KARG(FusedFwdP, w2);
     const auto R6_u = KARG(FusedFwdP, u);
     const auto R6_gp = KARG(FusedFwdP, gp);
+    const auto R7_b2 = KARG(FusedFwdP, b2);
+    const auto R7_drop_ff = KARG(FusedFwdP, drop_ff);
+    const auto R7_ff_b = KARG(FusedFwdP, ff_b);
+    const auto R7_ff_g = KARG(FusedFwdP, ff_g);
+    LnPre lnF;
     // ---- phase 6: erf-GELU pass (+ write-out for the backward), dense_2 (K split: group g owns inner columns [128g, 128g+128)) + dropout + residual + LN
     {
         // gelu(u) replaces the pre-activation in LDS, once per element (applying it in dense_2's operand loads would
@@ -922,6 +938,7 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
             st4(sU + r * FU + c4, g);
         }
         lds_barrier();
+        lnF = ln_pre(R7_b2, R7_ff_g, R7_ff_b, R7_drop_ff, dseed, tok0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -939,14 +956,10 @@ fused_layer_fwd_kernel(const FusedFwdP P_unused, const TAILP T_unused) {
     TopFwdHelpRegs<BF> TH;
     if constexpr (TAIL) { if (wave < 4) top_fwd_prefetch<BF, KOFF, false>(TR); else top_fwd_help_prefetch<BF, KOFF>(TH); }
     const auto R7_Xout = KARG(FusedFwdP, Xout);
-    const auto R7_b2 = KARG(FusedFwdP, b2);
-    const auto R7_drop_ff = KARG(FusedFwdP, drop_ff);
     const auto R7_eps = KARG(FusedFwdP, eps);
-    const auto R7_ff_b = KARG(FusedFwdP, ff_b);
-    const auto R7_ff_g = KARG(FusedFwdP, ff_g);
     const auto R7_rstd_ff = KARG(FusedFwdP, rstd_ff);
     const auto R7_xhat_ff = KARG(FusedFwdP, xhat_ff);
-    ln_rows_64<false, BF>(sX, sE, R7_b2, sH, R7_drop_ff, dseed, R7_ff_g, R7_ff_b, R7_eps, nullptr, 0.f, 1.f, tok0, L,
+    ln_rows_64<false, BF>(lnF, sX, sE, sH, R7_eps, nullptr, 0.f, 1.f, tok0, L,
                           TAIL ? sD : nullptr, R7_Xout, R7_xhat_ff, R7_rstd_ff, KARG(FusedFwdP, xout_f32) != 0, TAIL);
     STAMP(8);
     if constexpr (TAIL) {
