@@ -1,9 +1,12 @@
 """The one-row top block of the loss path as the TAIL of the forward launch of the block below it and as the HEAD of that
 block's backward launch (fused_layer.h TAILP / HEADP; plan option separate_top = 0, the default) against the same
-block as kernels of its own (separate_top = 1): the arithmetic is the same instruction for instruction, only the x / dX
-tiles stay in LDS instead of a round trip through global memory -- loss and every gradient must be bit-identical (the
-item table's up to the order of its atomic row additions), with
-dropout on (same Philox stream), in fp32 and in bf16 storage, for 2 and 3 blocks."""
+block as kernels of its own (separate_top = 1): the same formulas, the same Philox stream and the same saved tensors; the
+x / dX tiles stay in LDS instead of a round trip through global memory.  Until round 3 the two were the same instruction
+for instruction and this test asserted bit identity.  The fused variant now spreads the one-row chain over all 8 waves:
+its matrix-vector products sum in a different order (4 lane groups, then a swap-reduce), and the low-pass component of
+row L-1 is one projector row applied to the x tile instead of spectrum + synthesis -- the same numbers up to fp32
+rounding.  So: loss to 1e-6 relative, every gradient to 2e-6 relative L2 and 2e-5 of its largest entry elementwise, with
+dropout on, in fp32 and in bf16 storage (whose gates are the bf16 rounding of a tile entry), for 2 and 3 blocks."""
 import argparse
 
 import numpy as np
@@ -54,11 +57,15 @@ def test_top_block_inside_the_lower_blocks_launches_is_bit_identical(kw, storage
         kw["storage"] = "bf16"
     a = _run(_ns(**kw), 1)
     b = _run(_ns(**kw), 0)
+    rel, elem = (2e-6, 2e-5) if storage == "f32" else (6e-3, 4e-2)     # bf16: one flipped rounding of a saved activation = 2^-8 of it
     for (la, ga), (lb, gb) in zip(a, b):
-        assert la == lb
+        assert abs(la - lb) <= (1e-6 if storage == "f32" else 2e-3) * abs(la), (la, lb)
         assert set(ga) == set(gb)
         for k in ga:
-            if k == "item_embeddings.weight":      # lookup rows are scattered with float atomics: order-dependent last bits
-                np.testing.assert_allclose(ga[k], gb[k], rtol=0, atol=2e-7, err_msg=k)
-            else:
-                np.testing.assert_array_equal(ga[k], gb[k], err_msg=k)
+            x, y = ga[k].astype(np.float64), gb[k].astype(np.float64)
+            scale = max(np.abs(x).max(), 1e-30)
+            if k.endswith("key.bias"):             # analytically zero (softmax is shift-invariant): both are rounding noise
+                assert np.abs(x).max() <= 1e-5 and np.abs(y).max() <= 1e-5, k
+                continue
+            assert np.linalg.norm(x - y) <= rel * max(np.linalg.norm(x), 1e-30), (k, np.linalg.norm(x - y) / np.linalg.norm(x))
+            assert np.abs(x - y).max() <= elem * scale, (k, np.abs(x - y).max() / scale)
