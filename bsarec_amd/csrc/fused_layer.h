@@ -1153,6 +1153,8 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
         }
     }
     WFrag<MM, 64> wA, wB;
+    WFrag<MM, 32> wk4;                              // stage D's key-weight fragments (requested at the end of stage C)
+    f32x4 e_bt, e_x[2];                             // stage E's sqrt_beta / x tile rows (requested there too)
     load_wT<MM, 64, 256>(R1_w2, (long)KH * 256 + 128 * grp + col, wA);             // first dU block of this group
     // stage A1's operands are requested BEFORE the u tile: loads return in issue order, so the LayerNorm row pass waits
     // only for them while the 64 KB of u are still in flight
@@ -1699,6 +1701,18 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
             }
             lds_barrier();
         }
+        // requests of the next two stages, ahead of the write-out below (loads return in issue order; the stores do not hold
+        // them up): stage D's weight fragments, and stage E's x tile / sqrt_beta, which would otherwise be asked for at
+        // their point of use with the whole round trip exposed
+        {
+            const long wofs = (long)KH * 64 + col;
+            if (grp == 0) { load_wT<MM, 64, 64>(KARG(FusedBwdP, wq), wofs, wA); load_wT<MM, 32, 64>(KARG(FusedBwdP, wk), wofs, wk4); }
+            else { load_wT<MM, 32, 64>(KARG(FusedBwdP, wk), wofs + 32 * 64, wk4); load_wT<MM, 64, 64>(KARG(FusedBwdP, wv), wofs, wA); }
+            const float* const pX = KARG(FusedBwdP, X);
+            e_bt = gld4(KARG(FusedBwdP, sqrt_beta) + lc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) e_x[i] = ald4<BF>(pX, (tok0 + min(32 * i + lr, L - 1)) * 64 + lc);
+        }
         // dq, dk, dv -> global as whole rows, 16 B per lane (operands of the Q/K/V weight gradients)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1713,18 +1727,11 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     }
 
     STAMP(6);
-    const auto R7_wk = KARG(FusedBwdP, wk);
-    const auto R7_wq = KARG(FusedBwdP, wq);
-    const auto R7_wv = KARG(FusedBwdP, wv);
     // ---- stage D: dQ.Wq + dK.Wk + dV.Wv, K = 192 split: group 0 = dQ.Wq + dK[:, :32].Wk[:32], group 1 = the rest
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const long wofs = (long)KH * 64 + col;
-        WFrag<MM, 32> wk4;
-        if (grp == 0) { load_wT<MM, 64, 64>(R7_wq, wofs, wA); load_wT<MM, 32, 64>(R7_wk, wofs, wk4); }
-        else { load_wT<MM, 32, 64>(R7_wk, wofs + 32 * 64, wk4); load_wT<MM, 64, 64>(R7_wv, wofs, wA); }
         mma_w<MM, 64>((grp == 0 ? sQ : sV) + arow, wA, acc);
         mma_w<MM, 32>(sK + arow + 32 * grp, wk4, acc);
         float* part = grp == 0 ? sG : sPm;
@@ -1734,7 +1741,6 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
     lds_barrier();
 
     STAMP(7);
-    const auto R8_X = KARG(FusedBwdP, X);
     const auto R8_dX = KARG(FusedBwdP, dX);
     const auto R8_pbeta = KARG(FusedBwdP, pbeta);
     const auto R8_sqrt_beta = KARG(FusedBwdP, sqrt_beta);
@@ -1743,12 +1749,33 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
         float* sXin = sT;
         float* spec = sAcc;                            // [2][cb][2][64]  (sAcc is folded into sG first)
         float* part = (grp == 0 ? sQ : sV);            // [16][4][2][64] = 8192 floats per group (T2-T3 / T4-T5)
-        const f32x4 bt = gld4(R8_sqrt_beta + lc);
+        const f32x4 bt = e_bt;
         const f32x4 b2 = bt * bt, omb2 = 1.0f - b2;
+        // the embedding LayerNorm backward's operands and dropout masks (bottom block): asked for / evaluated here, used after
+        // the transforms below
+        float* const e_dz = KARG(FusedBwdP, e_dz);
+        const float* const e_dx_extra = KARG(FusedBwdP, e_dx_extra);
+        f32x4 g0 = {0, 0, 0, 0}, e_xh[2], e_ex[2], e_dm[2];
+        float e_rs[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { e_xh[i] = f32x4{0, 0, 0, 0}; e_ex[i] = e_xh[i]; e_dm[i] = e_xh[i]; e_rs[i] = 0.f; }
+        if (e_dz || e_dx_extra) {
+            const float* const e_xhat = KARG(FusedBwdP, e_xhat);
+            const float* const e_rstd = KARG(FusedBwdP, e_rstd);
+            const DropP e_drop = KARG(FusedBwdP, e_drop);
+            if (e_dz) g0 = gld4(KARG(FusedBwdP, e_g) + lc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int t = 32 * i + lr;
+                const long e = (tok0 + min(t, L - 1)) * 64 + lc;
+                if (e_dx_extra) e_ex[i] = gld4(e_dx_extra + e);
+                if (e_dz) { e_xh[i] = ald4<BF>(e_xhat, e); e_rs[i] = gld(e_rstd + tok0 + min(t, L - 1)); e_dm[i] = drop_mult4(e_drop, dseed, (uint64_t)e >> 2); }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 32 * i + lr;
-            f32x4 x = ald4<BF>(R8_X, (tok0 + min(r, L - 1)) * 64 + lc);
+            f32x4 x = e_x[i];
             if (r >= L) x = f32x4{0, 0, 0, 0};
             st4(sG + r * FS + lc, ld4(sG + r * FS + lc) + ld4(sPm + r * FS + lc) + ld4(sAcc + r * FS + lc));
             st4(sXin + r * FS + lc, x);
@@ -1797,13 +1824,6 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
             lds_barrier();
         }
         f32x4 sb = {0, 0, 0, 0}, sg0 = sb, sb0 = sb;
-        float* const e_dz = KARG(FusedBwdP, e_dz);
-        const float* const e_xhat = KARG(FusedBwdP, e_xhat);
-        const float* const e_rstd = KARG(FusedBwdP, e_rstd);
-        const DropP e_drop = KARG(FusedBwdP, e_drop);
-        const float* const e_dx_extra = KARG(FusedBwdP, e_dx_extra);
-        f32x4 g0 = {0, 0, 0, 0};
-        if (e_dz) g0 = gld4(KARG(FusedBwdP, e_g) + lc);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = 32 * i + lr;
@@ -1816,9 +1836,9 @@ fused_layer_bwd_kernel(const FusedBwdP P_unused, const HEADP H_unused) {
                 const f32x4 lowx = lowpass_tab(spec, t, lc, L, cb, sTab);
                 const f32x4 lowg = lowpass_tab(spec + cb * 128, t, lc, L, cb, sTab);
                 dx = ld4(sG + t * FS + lc) + b2 * df + lowg;
-                if (e_dx_extra) dx += gld4(e_dx_extra + e);
+                if (e_dx_extra) dx += e_ex[i];
                 sb += df * (xv - lowx);
-                if (e_dz) { xh = ald4<BF>(e_xhat, e); rs = gld(e_rstd + tok0 + t); dx = dx * drop_mult4(e_drop, dseed, (uint64_t)e >> 2); }
+                if (e_dz) { xh = e_xh[i]; rs = e_rs[i]; dx = dx * e_dm[i]; }
                 else ast4<BF>(R8_dX, e, dx);
             }
             if (e_dz) {                                     // embedding LayerNorm backward on the finished row
