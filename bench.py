@@ -615,6 +615,10 @@ def main():
         except Exception as e:                                      # never lose the headline line to a secondary measurement
             sec["C3"] = {"error": f"{type(e).__name__}: {e}"}
         try:
+            sec["C3_bf16"] = secondary_c3(dev, seqs, D, BSARecModel, Trainer, dtype="bf16")
+        except Exception as e:  # noqa: BLE001
+            sec["C3_bf16"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
             sec["C2_storage_bf16"] = secondary_bf16(a, dev, users, inputs, answers, D, BSARecModel, Trainer)
         except Exception as e:
             sec["C2_storage_bf16"] = {"error": f"{type(e).__name__}: {e}"}
@@ -717,12 +721,14 @@ def secondary_c4(dev, D, BSARecModel, Trainer, steps=40, warmup=5):
             "parity": "tests/test_gpu_config_shapes.py (oracle parity at V=20034; 2 ranks x 1024 == one process x 2048)"}
 
 
-def secondary_c3(dev, seqs, D, BSARecModel, Trainer, steps=15, warmup=3):
+def secondary_c3(dev, seqs, D, BSARecModel, Trainer, steps=15, warmup=3, dtype="f32"):
     """BASELINE config 3: the C1 interactions re-cut with L = 200, hidden 256, 4 heads, 4 layers, B = 256 --
-    generic tiled kernels, fp32.  Same step definition as the headline."""
+    generic tiled kernels.  Same step definition as the headline.  dtype "f32": the reference's arithmetic; "bf16": the
+    products of the block stack on bf16 MFMAs (operands rounded while staged into LDS, fp32 tensors / accumulation / head /
+    Adam -- csrc/gemm.h), judged at the bf16 gates of tests/test_gpu_bf16_generic.py."""
     import numpy as np
     import torch
-    a3 = argparse.Namespace(item_size=3417, hidden=256, seq_len=200, batch=256, layers=4, heads=4, dtype="f32")
+    a3 = argparse.Namespace(item_size=3417, hidden=256, seq_len=200, batch=256, layers=4, heads=4, dtype=dtype)
     m3 = model_args(a3)
     torch.manual_seed(42)
     model = BSARecModel(m3).to(dev)
@@ -735,6 +741,13 @@ def secondary_c3(dev, seqs, D, BSARecModel, Trainer, steps=15, warmup=3):
     dt, loss = timed_steps(Feed(tr, bt, dev), steps, warmup, torch.cuda.synchronize)
     assert np.isfinite(float(loss.item()))
     fl = train_flops_per_seq(a3, cb=2)
+    if dtype == "bf16":
+        return {"workload": "C3 in bf16: L=200 d=256 4 heads 4 BSARec layers, B=256, generic tiled kernels with bf16 products "
+                            "(fp32 tensors in HBM, operands rounded to bf16 in LDS, fp32 accumulate / LayerNorm / softmax / head / Adam)",
+                "dtype": "bf16", "value": round(256 * steps / dt, 1), "unit": "sequences/s", "ms_per_step": round(1e3 * dt / steps, 3),
+                "steps": steps, "step_bf16_mfma_frac": round(fl * 256 * steps / dt / (BF16_MFMA_PEAK_TFLOPS * 1e12), 5),
+                "parity_gates": "tests/test_gpu_bf16_generic.py: logits <= 5e-3 rel-Linf, loss <= 5e-4 rel, grads <= 2e-2 rel-L2 "
+                                "vs the reference's fp32 goldens and the fp32 oracle"}
     return {"workload": "C3: C1 interactions re-cut, L=200 d=256 4 heads 4 BSARec layers, B=256, fp32, generic tiled kernels",
             "value": round(256 * steps / dt, 1), "unit": "sequences/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
             "step_mfma_frac": round(fl * 256 * steps / dt / (FP32_MFMA_PEAK_TFLOPS * 1e12), 5)}

@@ -5,7 +5,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSAREC_LIB") or os.path.join(HERE, "libbsarec_hip.so")   # BSAREC_LIB: another build of the same ABI
 MAX_LAYERS = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 (BUF_LAYER_OUT, BUF_LOGITS, BUF_LOSS, BUF_DSP, BUF_HMIX, BUF_PROBS, BUF_DLAYER_IN, BUF_LOSS_ROWS, BUF_CTX,
  BUF_DLOGITS) = range(10)
@@ -128,6 +128,7 @@ EXPORTS = {
     "bsarec_plan_set_dense_grad_hook": (C.c_int, [C.c_void_p, HOOK, C.c_void_p, C.c_void_p]),
     "bsarec_buffer_is_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bsarec_plan_is_fused": (C.c_int, [C.c_void_p]),
+    "bsarec_config_is_fused": (C.c_int, [C.c_void_p]),
     "bsarec_plan_destroy": (None, [C.c_void_p]),
     "bsarec_buffer_offset": (C.c_long, [C.c_void_p, C.c_int, C.c_int]),
     "bsarec_step_begin": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -46,6 +46,7 @@ struct ProfState {                    // per plan (bsarec_profile_select / _read
     ~ProfState() { for (auto& e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }
 };
 static ProfState* prof_of(bsarec_plan* p);
+static bool bf_products_of(const bsarec_plan* p);     // cfg.storage = 1 on the generic tiled path: bf16 products (gemm.h)
 
 struct ProfScope {
     hipStream_t s; bool on; hipEvent_t stop;
@@ -76,11 +77,10 @@ static GemmP gemm_defaults(int M, int N, int K) {
     return P;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AXF, int BXF, bool BG, class Epi>
-static int launch_gemm(const GemmP& P, const XformP& X, const Epi& epi, float* bgrad, int nbatch, hipStream_t s,
-                       int kclass = BSAREC_K_NONE) {
-    auto kern = gemm_kernel<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, Epi>;
-    constexpr size_t smem = GemmSmem<BM, BN, AKM, BKM>::BYTES;
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AXF, int BXF, bool BG, bool BF, class Epi>
+static int launch_gemm_as(const GemmP& P, const XformP& X, const Epi& epi, float* bgrad, int nbatch, hipStream_t s, int kclass) {
+    auto kern = gemm_kernel<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, BF, Epi>;
+    constexpr size_t smem = GemmSmem<BM, BN, AKM, BKM, BF>::BYTES;
     static bool attr_done = false;
     if (!attr_done) {
         if (smem > 48 * 1024)
@@ -93,6 +93,16 @@ static int launch_gemm(const GemmP& P, const XformP& X, const Epi& epi, float* b
     ProfScope prof(kclass, s);
     hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), smem, s, P, X, epi, bgrad);
     return (int)hipGetLastError();
+}
+
+// fp32_only: the products of the loss head (logits and their backward) stay fp32 in the bf16-product mode, as they do under
+// the fused bf16 storage
+template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AXF, int BXF, bool BG, class Epi>
+static int launch_gemm(const GemmP& P, const XformP& X, const Epi& epi, float* bgrad, int nbatch, hipStream_t s,
+                       int kclass = BSAREC_K_NONE, bool fp32_only = false) {
+    if (!fp32_only && t_plan && bf_products_of(t_plan))
+        return launch_gemm_as<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, true, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
+    return launch_gemm_as<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, false, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
 }
 
 static XformP no_xform() { XformP X; memset(&X, 0, sizeof(X)); return X; }
@@ -116,7 +126,8 @@ struct LayerBufs {
 struct bsarec_plan {
     bsarec_config_t cfg;
     bsarec_tensors_t P, G, S;                  // parameters, gradients, bf16 shadow of the parameters (storage = 1)
-    bool bf;                                   // cfg.storage == 1
+    bool bf;                                   // cfg.storage == 1 at the fused shape: bf16 storage + bf16 MFMA in the block kernels
+    bool bf_products;                          // cfg.storage == 1 elsewhere: fp32 tensors, bf16 products in the tiled GEMMs (gemm.h)
     char* ws; size_t ws_bytes;
     uint64_t* state;
     const float* twiddle;
@@ -157,6 +168,7 @@ struct bsarec_plan {
     float* lookup_grad = nullptr;            // target of the embedding scatter when the dense dE is exchanged early
 };
 static ProfState* prof_of(bsarec_plan* p) { return &p->prof; }
+static bool bf_products_of(const bsarec_plan* p) { return p->bf_products; }
 struct PlanScope {                           // marks the plan a C call works on for this thread (nesting-safe)
     bsarec_plan* prev;
     explicit PlanScope(bsarec_plan* p) : prev(t_plan) { t_plan = p; }
@@ -201,12 +213,13 @@ static bool fused_shape_ok(const bsarec_config_t& c) {
 
 static void derive(bsarec_plan& p) {
     const bsarec_config_t& c = p.cfg;
-    p.bf = c.storage == 1;
+    p.fused = fused_shape_ok(c);
+    p.bf = c.storage == 1 && p.fused;
+    p.bf_products = c.storage == 1 && !p.fused;
     p.T = c.batch * c.seq_len;
     p.Lp = (int)rup(c.seq_len, 4);
     p.Vp = (int)rup(c.item_size, 4);
     p.dh = c.hidden / c.heads;
-    p.fused = fused_shape_ok(c);
     // LayerNorm gamma/beta partials: one row per 64-token block, or one per sequence on the fused path
     p.nblk = p.fused ? c.batch : cdiv(p.T, 64);
     p.rows_pb = p.fused ? c.seq_len : 64;
@@ -289,7 +302,6 @@ extern "C" int bsarec_abi_version(void) { return BSAREC_ABI_VERSION; }
 
 extern "C" size_t bsarec_workspace_bytes(const bsarec_config_t* cfg) {
     if (!cfg || check_cfg(*cfg) != 0) return 0;
-    if (cfg->storage == 1 && !fused_shape_ok(*cfg)) return 0;       // bf16 storage exists for the fused shape class only
     bsarec_plan p;
     p.cfg = *cfg;
     derive(p);
@@ -316,7 +328,7 @@ extern "C" int bsarec_plan_create(bsarec_plan_t** out, const bsarec_config_t* cf
                                   size_t workspace_bytes, void* state, const float* twiddle, void* stream) {
     if (!out || !cfg || !params || !workspace || !state || !twiddle) return -10;
     RET(check_cfg(*cfg));
-    if (cfg->storage == 1 && (!fused_shape_ok(*cfg) || !shadow)) return -15;
+    if (cfg->storage == 1 && fused_shape_ok(*cfg) && !shadow) return -15;     // (the generic path rounds its operands itself)
     if (((uintptr_t)workspace & 255) != 0) return -11;
     bsarec_plan* p = new bsarec_plan();
     p->cfg = *cfg;
@@ -442,6 +454,11 @@ extern "C" int bsarec_plan_set_dense_grad_hook(bsarec_plan_t* p, bsarec_hook_t h
 }
 
 extern "C" int bsarec_plan_is_fused(const bsarec_plan_t* p) { return p && p->fused ? 1 : 0; }
+extern "C" int bsarec_config_is_fused(const bsarec_config_t* cfg) {
+    if (!cfg) return -10;
+    RET(check_cfg(*cfg));
+    return fused_shape_ok(*cfg) ? 1 : 0;
+}
 
 extern "C" int bsarec_buffer_is_bf16(const bsarec_plan_t* p, int buffer, int layer) {
     if (!p || !p->bf) return 0;
@@ -907,7 +924,7 @@ extern "C" int bsarec_logits(bsarec_plan_t* p, void* stream) {
     g.Nb = c.item_size; g.lda = (long)L * d; g.ldb = d;
     g.A[0] = p->X[c.layers] + (long)(L - 1) * d; g.B[0] = p->P.item_emb;
     auto e = epi_linear<false, false, false>(p->logits, p->Vp);
-    return launch_gemm<64, 64, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, no_xform(), e, nullptr, 1, s, BSAREC_K_LOGITS);
+    return launch_gemm<64, 64, 2, 2, false, false, XF_NONE, XF_NONE, false>(g, no_xform(), e, nullptr, 1, s, BSAREC_K_LOGITS, true);
 }
 
 static int loss_impl(bsarec_plan_t* p, const int64_t* answers, void* stream, bool with_mean) {
@@ -1053,8 +1070,8 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
             LAUNCH(gemm_logits_bwd_kernel, dim3(G.tilesA + G.tilesB_m * p->vsplit), dim3(GEMM_THREADS), smem, s, G);
             HIPCHK(hipGetLastError());
         } else {                                   // wider hidden sizes: two plain launches (N needs several tiles)
-            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, false>(G.A, nox, G.EA, nullptr, 1, s)));
-            RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(G.B, nox, G.EB, nullptr, 1, s)));
+            RET((launch_gemm<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, false>(G.A, nox, G.EA, nullptr, 1, s, BSAREC_K_NONE, true)));
+            RET((launch_gemm<64, 64, 2, 2, false, true, XF_NONE, XF_NONE, false>(G.B, nox, G.EB, nullptr, 1, s, BSAREC_K_NONE, true)));
         }
     }
     // the dense item-table gradient is complete (enqueued): a data-parallel host may start exchanging it now
@@ -1265,9 +1282,10 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                     dw_np = 0; dw_nu = 0; DW.nsmall = 0; DW.small_slabs = 0;
                 }
             } else {
-            constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES;
             ProfScope prof(BSAREC_K_DW1, s);
-            LAUNCH(gemm_grouped_tn_kernel, dim3(tiles, ns), dim3(GEMM_THREADS), smem, s, G);
+            constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES, smem_bf = GemmSmem<64, 64, true, true, true>::BYTES;
+            if (p->bf_products) LAUNCH(gemm_grouped_tn_kernel<true>, dim3(tiles, ns), dim3(GEMM_THREADS), smem_bf, s, G);
+            else LAUNCH(gemm_grouped_tn_kernel<false>, dim3(tiles, ns), dim3(GEMM_THREADS), smem, s, G);
             HIPCHK(hipGetLastError());
             }
         }

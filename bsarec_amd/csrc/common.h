@@ -210,3 +210,24 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------
+// bf16 pieces shared by the bf16 modes (fused bf16 storage, bf16 products of the generic tiled GEMM): two bf16 per dword
+// (element 2j in the low half), v_cvt_pk_bf16_f32 rounding (nearest even), v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32 (round to nearest even)
+    const bf16x2_t r = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+__device__ __forceinline__ u32x4 pk8(const f32x4& a, const f32x4& b) {
+    return u32x4{pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w)};
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}

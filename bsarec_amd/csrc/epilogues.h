@@ -169,6 +169,7 @@ struct GroupedTN {
     int act;                        // which hidden_act (0 = gelu)
 };
 
+template <bool BF>          // BF: bf16 products (gemm.h), cfg.storage = 1 outside the fused shape class
 __global__ void __launch_bounds__(GEMM_THREADS)
 gemm_grouped_tn_kernel(const GroupedTN G) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -179,9 +180,9 @@ gemm_grouped_tn_kernel(const GroupedTN G) {
     XformP X;
     X.L = 0; X.Lp = 0; X.drop.thresh = 0; X.drop.scale = 1.f; X.drop.rng = nullptr; X.drop.site = 0; X.act = G.act;
     if (G.b_gelu[p])
-        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_GELU, true>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
+        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_GELU, true, BF>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
     else
-        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
+        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true, BF>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -106,22 +106,7 @@ __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 // the Linear weights from a bf16 shadow of the fp32 masters, and feed v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
 // LDS tiles, LayerNorm, softmax, GELU, dropout and all statistics stay fp32.
 // ---------------------------------------------------------------------------------------------
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32 (round to nearest even)
-    const bf16x2_t r = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, r);
-}
-__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
-__device__ __forceinline__ u32x4 pk8(const f32x4& a, const f32x4& b) {
-    return u32x4{pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w)};
-}
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
+// (u32x2 / u32x4, pk_bf16, bf_lo / bf_hi, pk8, mfma_bf16: common.h)
 // activation tensor accessors: 4 consecutive elements at element index e (16 B fp32 / 8 B bf16), or one element
 template <bool BF> __device__ __forceinline__ f32x4 ald4(const float* base, long e) {
     if constexpr (BF) {

@@ -14,6 +14,17 @@
 //     32x32 MFMA accumulators; global->register->LDS double buffering, one barrier per k-tile.
 //   * the epilogue always goes through an LDS image of the C tile so that every epilogue
 //     (bias, LayerNorm, softmax, gradient fix-ups) reads whole rows and stores 16 B per lane.
+//
+// bf16 products (BF = true; cfg.storage = 1 outside the fused shape class): the operands stay fp32 tensors in HBM, are
+// rounded to bf16 (nearest even) on their way INTO LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate):
+// one matrix instruction per 16-deep k-block where the fp32 form needs eight, and -- unlike v_mfma_f32_*_f32 on gfx950 --
+// off the vector ALU.  Epilogues, statistics and every tensor in memory are unchanged.  LDS images, in dwords of two bf16
+// (k = 2j in the low half of dword j):
+//   * "KC" operand: [row][16 + 4]; a loaded f32x4 becomes one ds_write_b64; lane (i, half) reads k = 16 blk + 8 half .. + 7 as
+//     one ds_read_b128 (rows 80 B apart: the 16-lane groups of a b128 read fall on distinct banks).
+//   * "KM" operand: a thread loads rows 4g .. 4g+3 of TWO consecutive k, packs the four (k, k + 1) pairs and writes the tile
+//     TRANSPOSED as [row][16 + 2] (four ds_write_b32, 2-way conflicts; 8 lanes = 128 contiguous bytes per global k row);
+//     lane (i, half) reads its 8 k as two ds_read_b64 (rows 72 B apart: conflict-free over the 64 banks).
 #pragma once
 #include "common.h"
 
@@ -53,10 +64,14 @@ struct TileCtx {          // what an epilogue needs to know about its tile
 // ---------------------------------------------------------------------------------------------
 // global -> registers -> LDS tile loader
 // ---------------------------------------------------------------------------------------------
-template <int R, bool KM, int XF>
+#define GEMM_LDK_KC 20      // bf16 images: dwords per row of a k-contiguous operand (16 k pairs + 4)
+#define GEMM_LDK_KM 18      //              dwords per row of a transposed k-major operand (16 k pairs + 2)
+
+template <int R, bool KM, int XF, bool BF = false>
 struct TileLoader {
     static constexpr int NV = R * GEMM_BK / 4 / GEMM_THREADS;
     static_assert(NV >= 1, "tile too small for 256 threads");
+    static_assert(!(BF && KM) || NV % 2 == 0, "bf16 k-major staging pairs two k rows per thread");
     f32x4 v[NV];
 
     __device__ __forceinline__ f32x4 xform(f32x4 x, int q, int key0, bool valid, const XformP& X, int zb) const {
@@ -73,6 +88,22 @@ struct TileLoader {
 
     int r0_, k0_, rlim_, klim_;     // tile origin / limits of the stage in flight (the transform needs them at store time)
 
+    // position of load p of this thread inside the tile: (k, first of 4 rows) of a k-major operand.  bf16 products: loads
+    // 2q and 2q + 1 take the SAME four rows at k = 2 kp and 2 kp + 1, with j = tid + 256 q, rows 4 ((j & 7) + 8 (j >> 7)),
+    // kp = (j >> 3) & 15 -- 8 lanes cover 128 contiguous bytes of a k row, a half-wave's transposed writes are 2-way.
+    static __device__ __forceinline__ void km_pos(int p, int& kk, int& rr) {
+        const int tid = threadIdx.x;
+        if (BF) {
+            const int j = tid + (p >> 1) * GEMM_THREADS;
+            kk = 2 * ((j >> 3) & 15) + (p & 1);
+            rr = ((j & 7) + 8 * (j >> 7)) << 2;
+        } else {
+            constexpr int RV = R / 4;
+            const int idx = tid + p * GEMM_THREADS;
+            kk = idx / RV; rr = (idx % RV) << 2;
+        }
+    }
+
     // rows [r0, r0+R) limited by rlim; k range [k0, k0+BK) limited by klim.  Only ISSUES the loads: the element
     // transform (GELU / dropout) is applied in store(), when the data is consumed -- applying it here would make
     // the wave wait for the round trip at issue time and serialise the prefetch.
@@ -87,8 +118,9 @@ struct TileLoader {
                 const int gr = r0 + (idx >> 3), gk = k0 + ((idx & 7) << 2);
                 if (gr < rlim && gk < klim) x = ld4(base + (long)gr * ld + gk);
             } else {
-                constexpr int RV = R / 4;
-                const int gk = k0 + idx / RV, gr = r0 + ((idx % RV) << 2);
+                int kk, rr;
+                km_pos(p, kk, rr);
+                const int gk = k0 + kk, gr = r0 + rr;
                 if (gk < klim) {
                     const float* src = base + (long)gk * ld + gr;
                     if (gr + 3 < rlim) x = ld4(src);
@@ -105,6 +137,39 @@ struct TileLoader {
 
     __device__ __forceinline__ void store(float* s, const XformP& X, int zb) const {
         const int tid = threadIdx.x;
+        if constexpr (BF) {
+            unsigned* su = reinterpret_cast<unsigned*>(s);
+            if (!KM) {
+#pragma unroll
+                for (int p = 0; p < NV; ++p) {
+                    const int idx = tid + p * GEMM_THREADS;
+                    f32x4 x = v[p];
+                    if (XF != XF_NONE) {
+                        const int gr = r0_ + (idx >> 3), gk = k0_ + ((idx & 7) << 2);
+                        x = xform(x, gr, gk, gr < rlim_ && gk < klim_, X, zb);
+                    }
+                    *reinterpret_cast<u32x2*>(su + (idx >> 3) * GEMM_LDK_KC + ((idx & 7) << 1)) = u32x2{pk_bf16(x.x, x.y), pk_bf16(x.z, x.w)};
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NV / 2; ++q) {
+                    int kk, rr;
+                    km_pos(2 * q, kk, rr);
+                    f32x4 x0 = v[2 * q], x1 = v[2 * q + 1];
+                    if (XF != XF_NONE) {
+                        const int gk = k0_ + kk, gr = r0_ + rr;
+                        x0 = xform(x0, gk, gr, gk < klim_ && gr < rlim_, X, zb);
+                        x1 = xform(x1, gk + 1, gr, gk + 1 < klim_ && gr < rlim_, X, zb);
+                    }
+                    unsigned* d = su + rr * GEMM_LDK_KM + (kk >> 1);
+                    d[0] = pk_bf16(x0.x, x1.x);
+                    d[GEMM_LDK_KM] = pk_bf16(x0.y, x1.y);
+                    d[2 * GEMM_LDK_KM] = pk_bf16(x0.z, x1.z);
+                    d[3 * GEMM_LDK_KM] = pk_bf16(x0.w, x1.w);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             const int idx = tid + p * GEMM_THREADS;
@@ -127,10 +192,10 @@ struct TileLoader {
     }
 };
 
-template <int BM, int BN, bool A_KM, bool B_KM>
+template <int BM, int BN, bool A_KM, bool B_KM, bool BF = false>
 struct GemmSmem {
-    static constexpr int A_TILE = A_KM ? GEMM_BK * BM : BM * (GEMM_BK + 4);
-    static constexpr int B_TILE = B_KM ? GEMM_BK * BN : BN * (GEMM_BK + 4);
+    static constexpr int A_TILE = BF ? BM * (A_KM ? GEMM_LDK_KM : GEMM_LDK_KC) : (A_KM ? GEMM_BK * BM : BM * (GEMM_BK + 4));
+    static constexpr int B_TILE = BF ? BN * (B_KM ? GEMM_LDK_KM : GEMM_LDK_KC) : (B_KM ? GEMM_BK * BN : BN * (GEMM_BK + 4));
     static constexpr int STAGE = 2 * (A_TILE + B_TILE);
     static constexpr int LDC = BN + 4;
     static constexpr int CT = BM * LDC;
@@ -141,7 +206,7 @@ struct GemmSmem {
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, class Epi>
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, bool BF = false, class Epi>
 __device__ __forceinline__ void
 gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ bgrad /* [nprob][nsplit][M] */,
           const int bx, const int by, const int bz, float* __restrict__ smem) {
@@ -150,9 +215,9 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA");
-    using SM = GemmSmem<BM, BN, A_KM, B_KM>;
-    constexpr int LDAS = A_KM ? BM : BK + 4;
-    constexpr int LDBS = B_KM ? BN : BK + 4;
+    using SM = GemmSmem<BM, BN, A_KM, B_KM, BF>;
+    constexpr int LDAS = BF ? (A_KM ? GEMM_LDK_KM : GEMM_LDK_KC) : (A_KM ? BM : BK + 4);
+    constexpr int LDBS = BF ? (B_KM ? GEMM_LDK_KM : GEMM_LDK_KC) : (B_KM ? BN : BK + 4);
     float* As0 = smem;
     float* As1 = smem + SM::A_TILE;
     float* Bs0 = smem + 2 * SM::A_TILE;
@@ -191,9 +256,9 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
     // Two register stages per operand: tile it+2 is requested while tile it is multiplied and tile it+1 waits in
     // registers for its turn to be written to LDS, so a global/L2 round trip has two whole k-steps to land (one
     // k-step of a 64x64 tile is only 16 MFMAs per wave -- shorter than the round trip).
-    TileLoader<BM, A_KM, AXF> la0, la1;
-    TileLoader<BN, B_KM, BXF> lb0, lb1;
-    auto issue = [&](int it, TileLoader<BM, A_KM, AXF>& la, TileLoader<BN, B_KM, BXF>& lb) {
+    TileLoader<BM, A_KM, AXF, BF> la0, la1;
+    TileLoader<BN, B_KM, BXF, BF> lb0, lb1;
+    auto issue = [&](int it, TileLoader<BM, A_KM, AXF, BF>& la, TileLoader<BN, B_KM, BXF, BF>& lb) {
         const int seg = (P.nseg > 1) ? it / ktiles : prob;
         const int kt = (P.nseg > 1) ? it % ktiles : it;
         const int k0 = kbeg + kt * BK;
@@ -201,6 +266,35 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
         lb.load(P.B[seg] + boff, P.ldb, ctx.n0, P.Nb, k0, B_KM ? kvend : kend);
     };
     auto compute = [&](const float* __restrict__ as, const float* __restrict__ bs) {
+        if constexpr (BF) {
+            // operand fragment of lane (row, half) for the 16-deep k-block kb: dwords 8 kb + 4 half .. + 3 of its row
+            auto frag = [&](const float* __restrict__ t, int r, int ld, bool km, int kb) -> u32x4 {
+                const unsigned* q = reinterpret_cast<const unsigned*>(t) + r * ld + kb * 8 + 4 * half;
+                if (!km) return *reinterpret_cast<const u32x4*>(q);
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(q), hi = *reinterpret_cast<const u32x2*>(q + 2);
+                return u32x4{lo.x, lo.y, hi.x, hi.y};
+            };
+#pragma unroll
+            for (int kb = 0; kb < BK / 16; ++kb) {
+                u32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = frag(as, wrow + i * 32 + l31, LDAS, A_KM, kb);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = frag(bs, wcol + j * 32 + l31, LDBS, B_KM, kb);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[i], bf[j], acc[i][j]);
+            }
+#ifndef EXP_NO_BGRAD
+            if (BGRAD && A_KM && by == 0 && tid < BM) {          // column sums of the (bf16-rounded) A tile
+                const unsigned* q = reinterpret_cast<const unsigned*>(as) + tid * LDAS;
+#pragma unroll
+                for (int k = 0; k < BK / 2; ++k) bsum += bf_lo(q[k]) + bf_hi(q[k]);
+            }
+#endif
+            return;
+        }
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
             f32x4 af[TM], bf[TN];
@@ -274,9 +368,9 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
     epi.template run<BM, BN>(Cs, ctx);
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, class Epi>
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, bool BF, class Epi>
 __global__ void __launch_bounds__(GEMM_THREADS)
 gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bgrad) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_body<BM, BN, WM, WN, A_KM, B_KM, AXF, BXF, BGRAD, Epi>(P, X, epi, bgrad, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    gemm_body<BM, BN, WM, WN, A_KM, B_KM, AXF, BXF, BGRAD, BF, Epi>(P, X, epi, bgrad, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }

@@ -82,8 +82,7 @@ class _Plan:
         nbytes = lib.bsarec_workspace_bytes(C.byref(self.cfg))
         if nbytes == 0:
             raise ValueError("configuration not supported by libbsarec_hip (see include/bsarec_hip.h limits: "
-                             "L <= 256, hidden <= 256 and % 4 == 0, head size % 4 == 0, cutoff_bins*hidden <= 8192; "
-                             "storage = bf16 needs the fused shape hidden = 64, L <= 64)")
+                             "L <= 256, hidden <= 256 and % 4 == 0, head size % 4 == 0, cutoff_bins*hidden <= 8192)")
         dev = model._arena.device
         self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
         off = (-self.ws.data_ptr()) % 256
@@ -91,7 +90,9 @@ class _Plan:
         self.ws.zero_()
         self.batch = batch
         self.handle = C.c_void_p()
-        self.bf16 = bool(self.cfg.storage)
+        # storage = bf16: bf16 TENSORS (and a bf16 shadow of the weights) exist at the fused shape only; elsewhere the generic
+        # kernels keep fp32 tensors and multiply in bf16 (include/bsarec_hip.h, bsarec_config_t.storage)
+        self.bf16 = bool(self.cfg.storage) and lib.bsarec_config_is_fused(C.byref(self.cfg)) == 1
         self.garena = model._garena if garena is None else garena
         pt, gt = model._tensor_struct(model._arena), model._tensor_struct(self.garena)
         st = model._tensor_struct(model._shadow_arena()) if self.bf16 else None

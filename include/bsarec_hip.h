@@ -17,7 +17,8 @@
  *   - fp32 arithmetic and fp32 tensors by default (the reference's arithmetic type); cfg.storage = 1 keeps the
  *     saved activations / inter-block gradients / a shadow of the Linear weights in bf16 and multiplies with
  *     bf16 MFMAs (fp32 accumulation, fp32 masters, LayerNorm / softmax / loss / Adam in fp32) at the fused
- *     shape; ids and answers are int64 as produced by the reference DataLoader (src/dataset.py:108-115).
+ *     shape, and multiplies with bf16 MFMAs on operands rounded while they are staged (fp32 tensors) at every
+ *     other shape; ids and answers are int64 as produced by the reference DataLoader (src/dataset.py:108-115).
  */
 #ifndef BSAREC_HIP_H
 #define BSAREC_HIP_H
@@ -30,7 +31,7 @@ extern "C" {
 #endif
 
 #define BSAREC_MAX_LAYERS 16
-#define BSAREC_ABI_VERSION 7
+#define BSAREC_ABI_VERSION 8
 
 /* Hyper-parameters the reference model reads from `args`
  * (src/utils.py:83-96; src/model/bsarec.py:71-88; src/model/_modules.py:79-87). */
@@ -52,9 +53,12 @@ typedef struct {
     /* ---- per-plan options; 0 selects the default everywhere, so a zero-filled tail is a valid configuration ---- */
     int hidden_act;     /* FeedForward activation (src/model/_modules.py:38-59, ACT2FN): 0 gelu (erf form, the default), 1 relu,
                          * 2 swish, 3 tanh, 4 sigmoid.  Non-default activations run on the generic tiled kernels */
-    int storage;        /* 0: fp32 everywhere (the reference's arithmetic); 1: bf16 storage of the saved activations and of a
-                         *    bf16 shadow of the Linear weights, bf16 MFMA with fp32 accumulation, fp32 master weights, fp32
-                         *    LayerNorm / softmax / loss / Adam (config C2; fused shape hidden = 64, L <= 64 only) */
+    int storage;        /* 0: fp32 everywhere (the reference's arithmetic); 1 (config C2 / the bf16 half of C3): bf16 MFMA with fp32
+                         *    accumulation, fp32 master weights, fp32 LayerNorm / softmax / loss head / Adam.  At the fused shape
+                         *    (hidden = 64, L <= 64) the saved activations, the inter-block gradients and a shadow of the Linear weights
+                         *    are STORED as bf16; at every other shape (generic tiled kernels) all tensors stay fp32 and the operands of
+                         *    every matrix product of the block stack are rounded to bf16 as they are staged into LDS
+                         *    (bsarec_buffer_is_bf16 = 0 everywhere, `shadow` unused) */
     int no_fused;       /* 1: never take the fused per-sequence block kernels (hidden = 64, L <= 64, cutoff_bins <= 8) */
     int no_prune_top;   /* 1: bsarec_forward_last evaluates the full top block (no one-row evaluation) */
     int dw_tiled;       /* 1: LDS-tiled grouped weight-gradient kernel at the fused shape too (default: direct split-K) */
@@ -123,7 +127,7 @@ size_t bsarec_workspace_bytes(const bsarec_config_t *cfg);
  * must hold bsarec_workspace_bytes(cfg) bytes, 256-byte aligned; `twiddle` is the float[2L] table
  * (cos, sin)(2 pi j / L) built on the host in double precision.  Enqueues one small H2D copy of the
  * reduction job table on `stream` and waits for it (the one synchronising call of the training path).
- * `shadow` (cfg.storage = 1 only, else null): the same tensor set as `params` but as bf16 arrays (uint16_t behind the
+ * `shadow` (cfg.storage = 1 at the fused shape only, else null / ignored): the same tensor set as `params` but as bf16 arrays (uint16_t behind the
  * float* fields) -- the bf16 shadow of the fp32 masters that the MFMA products read; only the six Linear weights of
  * every layer are used.  The caller keeps it current: bsarec_shadow_refresh after it changes the masters itself, or
  * bsarec_adam_t.shadow_bf16 so that the fused Adam writes both.
@@ -139,6 +143,8 @@ int bsarec_buffer_is_bf16(const bsarec_plan_t *plan, int buffer, int layer);
 
 /* 1 if the plan resolved to the fused per-sequence block kernels (hidden = 64, L <= 64, ...), 0 for the generic tiled kernels. */
 int bsarec_plan_is_fused(const bsarec_plan_t *plan);
+/* The same question before a plan exists (does cfg.storage = 1 need a `shadow`?): 1 fused, 0 generic, < 0 invalid cfg. */
+int bsarec_config_is_fused(const bsarec_config_t *cfg);
 void bsarec_plan_destroy(bsarec_plan_t *plan);
 
 /* Data-parallel bucketing: the dense part of the item-table gradient, dE = dlogits^T . h_last, is complete
