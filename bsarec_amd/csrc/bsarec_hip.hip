@@ -100,8 +100,14 @@ static int launch_gemm_as(const GemmP& P, const XformP& X, const Epi& epi, float
 template <int BM, int BN, int WM, int WN, bool AKM, bool BKM, int AXF, int BXF, bool BG, class Epi>
 static int launch_gemm(const GemmP& P, const XformP& X, const Epi& epi, float* bgrad, int nbatch, hipStream_t s,
                        int kclass = BSAREC_K_NONE, bool fp32_only = false) {
-    if (!fp32_only && t_plan && bf_products_of(t_plan))
+    if (!fp32_only && t_plan && bf_products_of(t_plan)) {
+        // token-parallel products (M = B L rows, one problem): a 64 x 64 tile issues ~120 instructions and 16 KB of fp32 operand
+        // loads per 0.26 MFLOP k-step, which is what bounds it once the matrix time is gone -- 128 x 128 tiles quarter that
+        if constexpr (BM == 64 && BN == 64 && !BG)
+            if (P.M >= 8192 && P.N >= 128 && nbatch == 1)
+                return launch_gemm_as<128, 128, WM, WN, AKM, BKM, AXF, BXF, BG, true, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
         return launch_gemm_as<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, true, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
+    }
     return launch_gemm_as<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, false, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
 }
 

@@ -369,8 +369,23 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, bool BF, class Epi>
-__global__ void __launch_bounds__(GEMM_THREADS)
+__global__ void __launch_bounds__(GEMM_THREADS, BF ? 2 : 1)
+// (bf16 products: <= 256 registers, i.e. two workgroups per CU for the 256-wide tiles too -- their matrix time no longer covers
+// the loads of a lone workgroup: C3 step 12.2 -> 10.3 ms.  The fp32 form loses with the same cap: 17.7 -> 18.4 ms, spills.)
 gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bgrad) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_body<BM, BN, WM, WN, A_KM, B_KM, AXF, BXF, BGRAD, BF, Epi>(P, X, epi, bgrad, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    // XCD-aware tile order.  The dispatcher deals consecutive workgroups to the 8 XCDs in turn and every XCD has its own L2:
+    // in launch order the N/BN workgroups that read one A row block would sit under 8 different L2s, and with m fastest
+    // they are a whole grid row apart in time as well -- at the C3 shape the 52 ... 210 MB activation operand was re-read
+    // from the Infinity Cache / HBM once per column tile (4 ... 16 times).  Here every XCD label (id % 8) takes ONE contiguous
+    // run of the (m, n) tile sequence with n fastest (bijective for any tile count): the column tiles of a row block run
+    // side by side under one L2, which also keeps the whole weight matrix.  A pure speed choice: any order is correct.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y > 1) {
+        const int gy = gridDim.y, nt = gridDim.x * gy, id = bx + gridDim.x * by;
+        const int q = nt >> 3, r = nt & 7, xcd = id & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        by = t % gy; bx = t / gy;
+    }
+    gemm_body<BM, BN, WM, WN, A_KM, B_KM, AXF, BXF, BGRAD, BF, Epi>(P, X, epi, bgrad, bx, by, blockIdx.z, smem);
 }
