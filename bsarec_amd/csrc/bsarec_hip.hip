@@ -239,7 +239,8 @@ static void derive(bsarec_plan& p) {
     p.embed_in_block = !c.separate_embed || p.bf;     // bf16 storage: X[0] is written by the block kernel only
     p.direct_dw = !c.dw_tiled && (long)p.T * 4 * c.hidden * 4 < (1L << 31);      // its operands sit behind 32-bit buffer offsets
     p.scatter_in_block = p.fused && p.direct_dw && !c.separate_embed;
-    long ch = rup(cdiv(p.T, want_splits), GEMM_BK);
+    // (bf16 storage: 64-aligned chunks -- a wave's quarter is then whole 16-row k-blocks of the bf16 matrix instruction)
+    long ch = rup(cdiv(p.T, want_splits), p.bf ? 2 * GEMM_BK : GEMM_BK);
     if (ch < 64) ch = 64;
     if (ch > 2048) ch = 2048;
     p.kchunk = (int)ch;

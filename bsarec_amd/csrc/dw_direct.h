@@ -35,7 +35,7 @@ struct DwProblem {
     float* bslab;                       // [nslab][M]
     int gelu;                           // erf-GELU on the activation operand while loading (dW2 = dT2^T . gelu(u))
     int bf16;                           // both operands are bf16 tensors (cfg.storage = 1): lda / ldb still count elements; the
-                                        // products stay fp32 MFMA on the widened values (the kernel is bound by operand bytes)
+                                        // products run on the bf16 matrix cores (dw_loop_m; with `gelu`: widened, fp32 MFMA)
 };
 
 struct DwUnit { short prob, m0, n0, pad; };
@@ -124,6 +124,61 @@ __device__ __forceinline__ void dw_loop(__amdgpu_buffer_rsrc_t ra, __amdgpu_buff
     }
 }
 
+// bf16 tensors (cfg.storage = 1) multiplied on the bf16 matrix cores: v_mfma_f32_32x32x16_bf16 wants 8 consecutive k (token
+// rows) of ONE column packed in a lane, the tensors are token-major.  One k-block = 16 token rows; lane half h loads rows
+// 8h .. 8h+7 as 8 dwords (its two adjacent columns of each operand, as before) and forms the (row 2j, row 2j+1) pair of each
+// column with one byte permute: 32 permutes + 4 matrix instructions per 16 rows where the widening form (DwStage<true> +
+// fp32 MFMA above) spends 64 conversions + 32 fp32 MFMAs = ~2,100 cycles of the SIMD's vector ALU.
+struct DwStageM { unsigned a[8]; unsigned b[8]; };
+__device__ __forceinline__ void dw_issue_m(DwStageM& st, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob,
+                                           int soa, int sob, int rowa, int rowb) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        st.a[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ra, voa, soa + s * rowa, 0);
+        st.b[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rb, vob, sob + s * rowb, 0);
+    }
+}
+// nkb: k-blocks of 16 rows; crow: first row of this lane half's 8; BIAS: also the column sums of the gradient operand
+template <bool MASK, bool BIAS, int STAGES>
+__device__ __forceinline__ void dw_loop_m(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob, int soa, int sob,
+                                          int rowa, int rowb, int nkb, int crow, int kend, f32x16 (&acc)[2][2], f32x2& bs) {
+    DwStageM st[STAGES];
+#pragma unroll
+    for (int u = 0; u < STAGES; ++u) {
+        dw_issue_m(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
+        soa += 16 * rowa; sob += 16 * rowb;
+    }
+    for (int kb = 0; kb < nkb; kb += STAGES) {
+#pragma unroll
+        for (int u = 0; u < STAGES; ++u) {
+            if (kb + u >= nkb) break;
+            DwStageM& cur = st[u];
+            u32x4 a0, a1, b0, b1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned x0 = cur.a[2 * j], x1 = cur.a[2 * j + 1], y0 = cur.b[2 * j], y1 = cur.b[2 * j + 1];
+                if (MASK) {
+                    const bool ok0 = crow + 2 * j < kend, ok1 = crow + 2 * j + 1 < kend;
+                    x0 = ok0 ? x0 : 0u; y0 = ok0 ? y0 : 0u; x1 = ok1 ? x1 : 0u; y1 = ok1 ? y1 : 0u;
+                }
+                a0[j] = (x0 & 0xFFFFu) | (x1 << 16); a1[j] = (x0 >> 16) | (x1 & 0xFFFF0000u);
+                b0[j] = (y0 & 0xFFFFu) | (y1 << 16); b1[j] = (y0 >> 16) | (y1 & 0xFFFF0000u);
+                if (BIAS) { bs.x += bf_lo(x0) + bf_lo(x1); bs.y += bf_hi(x0) + bf_hi(x1); }
+            }
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+            crow += 16;
+            __builtin_amdgcn_sched_barrier(0);
+            dw_issue_m(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
+            soa += 16 * rowa; sob += 16 * rowb;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+#define DW_STAGES_M 3         // 48 token rows in flight per wave (the widening form: 5 x 8)
+
 // One workgroup = one (problem, 64 x 64 tile, slab slice): its 4 waves take the 4 quarters of the slice, meet in LDS,
 // wave 0 writes the slab.
 // STAGES = k-blocks in flight per wave = the granule the wave's k range is rounded up to: 5 for the block weight
@@ -165,7 +220,16 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
             if (full) dw_loop<false, false, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
             else dw_loop<false, true, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
         }
-        if (Q.bf16) { DW_RUN(true) } else { DW_RUN(false) }
+        if (Q.bf16 && !Q.gelu) {                             // bf16 operands on the bf16 matrix cores (16-row k-blocks)
+            const int nkb16 = (kend - kbeg + 15) >> 4;
+            const int voa_m = 8 * half * rowa + (m0 + 2 * l31) * 2, vob_m = 8 * half * rowb + (n0 + 2 * l31) * 2;
+            const int crow_m = kbeg + 8 * half;
+            const bool full16 = kbeg + 16 * nkb16 <= kend, bias = Q.bslab != nullptr && n0 == 0;
+            if (full16) {
+                if (bias) dw_loop_m<false, true, DW_STAGES_M>(ra, rb, voa_m, vob_m, soa, sob, rowa, rowb, nkb16, crow_m, kend, acc, bs);
+                else dw_loop_m<false, false, DW_STAGES_M>(ra, rb, voa_m, vob_m, soa, sob, rowa, rowb, nkb16, crow_m, kend, acc, bs);
+            } else dw_loop_m<true, true, DW_STAGES_M>(ra, rb, voa_m, vob_m, soa, sob, rowa, rowb, nkb16, crow_m, kend, acc, bs);
+        } else if (Q.bf16) { DW_RUN(true) } else { DW_RUN(false) }
 #undef DW_RUN
     }
     // bias gradient: column sums of the gradient operand; the two lane halves hold different token rows
