@@ -91,7 +91,7 @@ static int launch_gemm_as(const GemmP& P, const XformP& X, const Epi& epi, float
     dim3 grid(cdiv(P.M, BM), cdiv(P.N, BN), nbatch * P.nprob * P.nsplit);
     if (g_dry) return 0;
     ProfScope prof(kclass, s);
-    hipLaunchKernelGGL(kern, grid, dim3(GEMM_THREADS), smem, s, P, X, epi, bgrad);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, s, P, X, epi, bgrad);
     return (int)hipGetLastError();
 }
 
@@ -108,7 +108,12 @@ static int launch_gemm(const GemmP& P, const XformP& X, const Epi& epi, float* b
                 return launch_gemm_as<128, 128, WM, WN, AKM, BKM, AXF, BXF, BG, true, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
         return launch_gemm_as<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, true, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
     }
-    return launch_gemm_as<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, false, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
+    // fp32, 256-wide tiles (LayerNorm / softmax / dS epilogues at hidden or L > 128): 8 waves as 2 x 4 -- the 92 KB of
+    // fp32 staging allow one workgroup per CU, and four waves at 344 registers left every SIMD with a single wave
+    if constexpr (BN == 256 && WM * WN == 4)
+        return launch_gemm_as<BM, BN, 2, 4, AKM, BKM, AXF, BXF, BG, false, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
+    else
+        return launch_gemm_as<BM, BN, WM, WN, AKM, BKM, AXF, BXF, BG, false, Epi>(P, X, epi, bgrad, nbatch, s, kclass);
 }
 
 static XformP no_xform() { XformP X; memset(&X, 0, sizeof(X)); return X; }

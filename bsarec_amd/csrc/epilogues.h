@@ -15,11 +15,11 @@ struct EpiLinear {
     const float* U; long ldu;
     int act;                           // GGRAD: which hidden_act's derivative (0 = gelu)
 
-    template <int BM, int BN>
+    template <int BM, int BN, int NT = GEMM_THREADS>
     __device__ __forceinline__ void run(const float* Cs, const TileCtx& c) const {
         constexpr int LDC = BN + 4, CV = BN / 4;
         float* out = C[c.prob] + (long)c.b * c_sb + (long)c.hh * c_sh + (long)c.split * c_split;
-        for (int idx = threadIdx.x; idx < BM * CV; idx += GEMM_THREADS) {
+        for (int idx = threadIdx.x; idx < BM * CV; idx += NT) {
             const int r = idx / CV, lc = (idx % CV) << 2;
             const int m = c.m0 + r, n = c.n0 + lc;
             if (m >= c.M || n >= c.N) continue;
@@ -47,9 +47,9 @@ struct EpiLN {
     float* Y; float* xhat; float* rstd;
     const float* dsp; float alpha, oma;
 
-    template <int BM, int BN>
+    template <int BM, int BN, int NT = GEMM_THREADS>
     __device__ __forceinline__ void run(const float* Cs, const TileCtx& c) const {
-        constexpr int LDC = BN + 4, LPR = BN / 4, RPP = GEMM_THREADS / LPR;
+        constexpr int LDC = BN + 4, LPR = BN / 4, RPP = NT / LPR;
         const int N = c.N;
         const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
         const bool colok = lc < N;
@@ -90,9 +90,9 @@ struct EpiLN {
 struct EpiSoftmax {
     const int* ids; int L, Lp; float sqrt_dh; float* P;
 
-    template <int BM, int BN>
+    template <int BM, int BN, int NT = GEMM_THREADS>
     __device__ __forceinline__ void run(const float* Cs, const TileCtx& c) const {
-        constexpr int LDC = BN + 4, LPR = BN / 4, RPP = GEMM_THREADS / LPR;
+        constexpr int LDC = BN + 4, LPR = BN / 4, RPP = NT / LPR;
         const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
         bool kvalid[4];
 #pragma unroll
@@ -129,9 +129,9 @@ struct EpiSoftmax {
 struct EpiDS {
     const float* P; DropP drop; int L, Lp; float sqrt_dh; float* dS;
 
-    template <int BM, int BN>
+    template <int BM, int BN, int NT = GEMM_THREADS>
     __device__ __forceinline__ void run(const float* Cs, const TileCtx& c) const {
-        constexpr int LDC = BN + 4, LPR = BN / 4, RPP = GEMM_THREADS / LPR;
+        constexpr int LDC = BN + 4, LPR = BN / 4, RPP = NT / LPR;
         const int lr = threadIdx.x / LPR, lc = (threadIdx.x % LPR) << 2;
         for (int r = lr; r < BM; r += RPP) {
             const int q = c.m0 + r;

@@ -10,8 +10,9 @@
 //     B (a sum over k does not care); the +4 pad makes the 16-lane b128 groups conflict-free.
 //   * an operand whose row index is contiguous ("KM": A^T or B^T products) is staged k-major
 //     [BK][rows] by a straight 16-byte copy and read with four conflict-free ds_read_b32.
-//   * 256 threads = 4 waves arranged WM x WN; each wave owns (BM/WM) x (BN/WN) of the tile as
-//     32x32 MFMA accumulators; global->register->LDS double buffering, one barrier per k-tile.
+//   * 256 threads = 4 waves arranged WM x WN (512 = 8 waves as 2 x 4 for the 256-wide fp32 tiles: their 92 KB of staging
+//     allow one workgroup per CU, and 4 waves of 344 registers left every SIMD with ONE wave); each wave owns
+//     (BM/WM) x (BN/WN) of the tile as 32x32 MFMA accumulators; global->register->LDS double buffering, one barrier per k-tile.
 //   * the epilogue always goes through an LDS image of the C tile so that every epilogue
 //     (bias, LayerNorm, softmax, gradient fix-ups) reads whole rows and stores 16 B per lane.
 //
@@ -67,10 +68,10 @@ struct TileCtx {          // what an epilogue needs to know about its tile
 #define GEMM_LDK_KC 20      // bf16 images: dwords per row of a k-contiguous operand (16 k pairs + 4)
 #define GEMM_LDK_KM 18      //              dwords per row of a transposed k-major operand (16 k pairs + 2)
 
-template <int R, bool KM, int XF, bool BF = false>
+template <int R, bool KM, int XF, bool BF = false, int NT = GEMM_THREADS>
 struct TileLoader {
-    static constexpr int NV = R * GEMM_BK / 4 / GEMM_THREADS;
-    static_assert(NV >= 1, "tile too small for 256 threads");
+    static constexpr int NV = R * GEMM_BK / 4 / NT;
+    static_assert(NV >= 1, "tile too small for the workgroup");
     static_assert(!(BF && KM) || NV % 2 == 0, "bf16 k-major staging pairs two k rows per thread");
     f32x4 v[NV];
 
@@ -94,12 +95,12 @@ struct TileLoader {
     static __device__ __forceinline__ void km_pos(int p, int& kk, int& rr) {
         const int tid = threadIdx.x;
         if (BF) {
-            const int j = tid + (p >> 1) * GEMM_THREADS;
+            const int j = tid + (p >> 1) * NT;
             kk = 2 * ((j >> 3) & 15) + (p & 1);
             rr = ((j & 7) + 8 * (j >> 7)) << 2;
         } else {
             constexpr int RV = R / 4;
-            const int idx = tid + p * GEMM_THREADS;
+            const int idx = tid + p * NT;
             kk = idx / RV; rr = (idx % RV) << 2;
         }
     }
@@ -112,7 +113,7 @@ struct TileLoader {
         r0_ = r0; k0_ = k0; rlim_ = rlim; klim_ = klim;
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            const int idx = tid + p * GEMM_THREADS;
+            const int idx = tid + p * NT;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
             if (!KM) {
                 const int gr = r0 + (idx >> 3), gk = k0 + ((idx & 7) << 2);
@@ -142,7 +143,7 @@ struct TileLoader {
             if (!KM) {
 #pragma unroll
                 for (int p = 0; p < NV; ++p) {
-                    const int idx = tid + p * GEMM_THREADS;
+                    const int idx = tid + p * NT;
                     f32x4 x = v[p];
                     if (XF != XF_NONE) {
                         const int gr = r0_ + (idx >> 3), gk = k0_ + ((idx & 7) << 2);
@@ -172,7 +173,7 @@ struct TileLoader {
         }
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
-            const int idx = tid + p * GEMM_THREADS;
+            const int idx = tid + p * NT;
             f32x4 x = v[p];
             if (!KM) {
                 if (XF != XF_NONE) {
@@ -210,7 +211,8 @@ template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF
 __device__ __forceinline__ void
 gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ bgrad /* [nprob][nsplit][M] */,
           const int bx, const int by, const int bz, float* __restrict__ smem) {
-    static_assert(WM * WN == 4, "4 waves");
+    constexpr int NT = 64 * WM * WN;                 // 4 waves (256 threads) or, for the 256-wide fp32 tiles, 8 (2 x 4)
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves");
     constexpr int BK = GEMM_BK;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -256,9 +258,9 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
     // Two register stages per operand: tile it+2 is requested while tile it is multiplied and tile it+1 waits in
     // registers for its turn to be written to LDS, so a global/L2 round trip has two whole k-steps to land (one
     // k-step of a 64x64 tile is only 16 MFMAs per wave -- shorter than the round trip).
-    TileLoader<BM, A_KM, AXF, BF> la0, la1;
-    TileLoader<BN, B_KM, BXF, BF> lb0, lb1;
-    auto issue = [&](int it, TileLoader<BM, A_KM, AXF, BF>& la, TileLoader<BN, B_KM, BXF, BF>& lb) {
+    TileLoader<BM, A_KM, AXF, BF, NT> la0, la1;
+    TileLoader<BN, B_KM, BXF, BF, NT> lb0, lb1;
+    auto issue = [&](int it, TileLoader<BM, A_KM, AXF, BF, NT>& la, TileLoader<BN, B_KM, BXF, BF, NT>& lb) {
         const int seg = (P.nseg > 1) ? it / ktiles : prob;
         const int kt = (P.nseg > 1) ? it % ktiles : it;
         const int k0 = kbeg + kt * BK;
@@ -365,11 +367,11 @@ gemm_body(const GemmP& P, const XformP& X, const Epi& epi, float* __restrict__ b
                 Cs[row * SM::LDC + wcol + j * 32 + l31] = acc[i][j][r];
             }
     __syncthreads();
-    epi.template run<BM, BN>(Cs, ctx);
+    epi.template run<BM, BN, NT>(Cs, ctx);
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int AXF, int BXF, bool BGRAD, bool BF, class Epi>
-__global__ void __launch_bounds__(GEMM_THREADS, BF ? 2 : 1)
+__global__ void __launch_bounds__(64 * WM * WN, (BF && WM * WN == 4) ? 2 : 1)
 // (bf16 products: <= 256 registers, i.e. two workgroups per CU for the 256-wide tiles too -- their matrix time no longer covers
 // the loads of a lone workgroup: C3 step 12.2 -> 10.3 ms.  The fp32 form loses with the same cap: 17.7 -> 18.4 ms, spills.)
 gemm_kernel(const GemmP P, const XformP X, const Epi epi, float* __restrict__ bgrad) {
