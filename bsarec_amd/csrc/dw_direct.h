@@ -183,7 +183,9 @@ __device__ __forceinline__ void dw_loop_m(__amdgpu_buffer_rsrc_t ra, __amdgpu_bu
 // wave 0 writes the slab.
 // STAGES = k-blocks in flight per wave = the granule the wave's k range is rounded up to: 5 for the block weight
 // gradients (10 k-blocks per wave at C1), 4 for the logits backward (8 resp. 16 k-blocks per wave: no padding MFMAs).
-template <int STAGES = DW_STAGES>
+// BFM: the instantiation for plans with bf16 storage -- bf16 operands go to the bf16 matrix cores (dw_loop_m); the fp32
+// instantiation (every other plan, the logits backward) carries neither that loop nor the widening one
+template <int STAGES = DW_STAGES, bool BFM = false>
 __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, int slab, float (*red)[66][64]) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
@@ -220,6 +222,7 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
             if (full) dw_loop<false, false, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
             else dw_loop<false, true, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
         }
+        if constexpr (BFM) {
         if (Q.bf16 && !Q.gelu) {                             // bf16 operands on the bf16 matrix cores (16-row k-blocks)
             const int nkb16 = (kend - kbeg + 15) >> 4;
             const int voa_m = 8 * half * rowa + (m0 + 2 * l31) * 2, vob_m = 8 * half * rowb + (n0 + 2 * l31) * 2;
@@ -230,6 +233,7 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
                 else dw_loop_m<false, false, DW_STAGES_M>(ra, rb, voa_m, vob_m, soa, sob, rowa, rowb, nkb16, crow_m, kend, acc, bs);
             } else dw_loop_m<true, true, DW_STAGES_M>(ra, rb, voa_m, vob_m, soa, sob, rowa, rowb, nkb16, crow_m, kend, acc, bs);
         } else if (Q.bf16) { DW_RUN(true) } else { DW_RUN(false) }
+        } else { DW_RUN(false) }
 #undef DW_RUN
     }
     // bias gradient: column sums of the gradient operand; the two lane halves hold different token rows
@@ -278,6 +282,7 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
 // too, as the workgroups after the weight-gradient ones: light, latency-bound blocks that fill the slots the big
 // workgroups leave free instead of a launch of their own (11.6 us + a launch boundary at C1).
 struct ScatterP { const float* de; const int* ids32; int T; float* dE; int nblocks; };
+template <bool BFM>
 __global__ void __launch_bounds__(256)
 dw_direct_kernel(const DwP G, const TickP tk, const ScatterP sc) {
     __shared__ __attribute__((aligned(16))) float red[3][66][64];      // accumulators (64) + bias sums (2) of waves 1..3
@@ -308,7 +313,7 @@ dw_direct_kernel(const DwP G, const TickP tk, const ScatterP sc) {
     const DwUnit u = G.U[ui];
     const DwProblem& Q = G.P[u.prob];
     if (slab >= Q.nslab) return;
-    dw_wg_body(Q, u.m0, u.n0, slab, red);
+    dw_wg_body<DW_STAGES, BFM>(Q, u.m0, u.n0, slab, red);
 }
 
 // =============================================================================================
