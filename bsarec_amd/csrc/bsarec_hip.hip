@@ -1058,7 +1058,9 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
         H.nsplit = p->vsplit; H.slab = p->dlast_slab;
         const int tiles = cdiv(c.item_size, 64);
         if (!dw_problem_ok(q) || !dh_problem_ok(H)) return -21;
-        LAUNCH(logits_bwd_direct_kernel, dim3(tiles + cdiv(cdiv(B, 32) * p->vsplit, 4)), dim3(256), 0, s, q, tiles, H);
+        const dim3 lb_grid(tiles + cdiv(cdiv(B, 32) * p->vsplit, 4));
+        if (p->bf) LAUNCH(logits_bwd_direct_kernel<true>, lb_grid, dim3(256), 0, s, q, tiles, H);
+        else LAUNCH(logits_bwd_direct_kernel<false>, lb_grid, dim3(256), 0, s, q, tiles, H);
         HIPCHK(hipGetLastError());
     } else
     // dE (dense, logits path) = dlogits^T . h_last  [V, d] (overwrites the gradient buffer) and the split-K slabs of

@@ -177,6 +177,53 @@ __device__ __forceinline__ void dw_loop_m(__amdgpu_buffer_rsrc_t ra, __amdgpu_bu
         }
     }
 }
+// The same 16-row k-blocks for fp32 operands whose PRODUCT may be bf16 (the loss head under bf16 storage: d loss / d logits and
+// h_last are fp32 tensors): lane half h loads rows 8h .. 8h+7 as 8 float2 and rounds the (row 2j, row 2j+1) pairs of its two
+// columns with v_cvt_pk_bf16_f32 -- 16 conversions + 4 matrix instructions per 16 rows instead of 32 fp32 MFMAs.
+struct DwStageC { f32x2 a[8]; f32x2 b[8]; };
+__device__ __forceinline__ void dw_issue_c(DwStageC& st, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob,
+                                           int soa, int sob, int rowa, int rowb) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { st.a[s] = bld2(ra, voa, soa + s * rowa); st.b[s] = bld2(rb, vob, sob + s * rowb); }
+}
+template <bool MASK, int STAGES>
+__device__ __forceinline__ void dw_loop_c(__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int voa, int vob, int soa, int sob,
+                                          int rowa, int rowb, int nkb, int crow, int kend, f32x16 (&acc)[2][2]) {
+    DwStageC st[STAGES];
+#pragma unroll
+    for (int u = 0; u < STAGES; ++u) {
+        dw_issue_c(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
+        soa += 16 * rowa; sob += 16 * rowb;
+    }
+    for (int kb = 0; kb < nkb; kb += STAGES) {
+#pragma unroll
+        for (int u = 0; u < STAGES; ++u) {
+            if (kb + u >= nkb) break;
+            DwStageC& cur = st[u];
+            u32x4 a0, a1, b0, b1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x2 x0 = cur.a[2 * j], x1 = cur.a[2 * j + 1], y0 = cur.b[2 * j], y1 = cur.b[2 * j + 1];
+                if (MASK) {
+                    const bool ok0 = crow + 2 * j < kend, ok1 = crow + 2 * j + 1 < kend;
+                    if (!ok0) { x0 = f32x2{0.f, 0.f}; y0 = x0; }
+                    if (!ok1) { x1 = f32x2{0.f, 0.f}; y1 = x1; }
+                }
+                a0[j] = pk_bf16(x0.x, x1.x); a1[j] = pk_bf16(x0.y, x1.y);
+                b0[j] = pk_bf16(y0.x, y1.x); b1[j] = pk_bf16(y0.y, y1.y);
+            }
+            acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+            crow += 16;
+            __builtin_amdgcn_sched_barrier(0);
+            dw_issue_c(st[u], ra, rb, voa, vob, soa, sob, rowa, rowb);
+            soa += 16 * rowa; sob += 16 * rowb;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 #define DW_STAGES_M 3         // 48 token rows in flight per wave (the widening form: 5 x 8)
 
 // One workgroup = one (problem, 64 x 64 tile, slab slice): its 4 waves take the 4 quarters of the slice, meet in LDS,
@@ -185,7 +232,8 @@ __device__ __forceinline__ void dw_loop_m(__amdgpu_buffer_rsrc_t ra, __amdgpu_bu
 // gradients (10 k-blocks per wave at C1), 4 for the logits backward (8 resp. 16 k-blocks per wave: no padding MFMAs).
 // BFM: the instantiation for plans with bf16 storage -- bf16 operands go to the bf16 matrix cores (dw_loop_m); the fp32
 // instantiation (every other plan, the logits backward) carries neither that loop nor the widening one
-template <int STAGES = DW_STAGES, bool BFM = false>
+// CVT: fp32 operands, bf16 product (dw_loop_c; the logits backward of a bf16-storage plan; no bias sums on that path)
+template <int STAGES = DW_STAGES, bool BFM = false, bool CVT = false>
 __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, int slab, float (*red)[66][64]) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
@@ -222,7 +270,13 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
             if (full) dw_loop<false, false, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
             else dw_loop<false, true, BFV, STAGES>(ra, rb, voa, vob, soa, sob, rowa, rowb, nkb, crow, kend, acc, bs); \
         }
-        if constexpr (BFM) {
+        if constexpr (CVT) {
+            const int nkb16 = (kend - kbeg + 15) >> 4;
+            const int voa_c = 8 * half * rowa + (m0 + 2 * l31) * 4, vob_c = 8 * half * rowb + (n0 + 2 * l31) * 4;
+            const int crow_c = kbeg + 8 * half;
+            if (kbeg + 16 * nkb16 <= kend) dw_loop_c<false, STAGES>(ra, rb, voa_c, vob_c, soa, sob, rowa, rowb, nkb16, crow_c, kend, acc);
+            else dw_loop_c<true, STAGES>(ra, rb, voa_c, vob_c, soa, sob, rowa, rowb, nkb16, crow_c, kend, acc);
+        } else if constexpr (BFM) {
         if (Q.bf16 && !Q.gelu) {                             // bf16 operands on the bf16 matrix cores (16-row k-blocks)
             const int nkb16 = (kend - kbeg + 15) >> 4;
             const int voa_m = 8 * half * rowa + (m0 + 2 * l31) * 2, vob_m = 8 * half * rowb + (n0 + 2 * l31) * 2;
@@ -329,7 +383,7 @@ struct DhP {
     float* slab;                       // [nsplit][B][64]
 };
 
-template <int STAGES = DW_STAGES>
+template <int STAGES = DW_STAGES, bool CVT = false>
 __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
@@ -346,6 +400,48 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
         // descriptors over exactly dlogits [B][lda] and E [V][64]: prefetch past either end reads 0, not memory
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)G.A, 0, (int)((long)G.B * G.lda * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)G.E, 0, (int)((long)G.V * 256), 0x00020000);
+        if constexpr (CVT) {
+            // bf16 product of the fp32 operands: 16 catalogue columns per k-block, lane half h takes columns 8h .. 8h+7 of its
+            // batch row (two 16-byte loads, rounded in pairs) and rows 8h .. 8h+7 of E for its two feature columns
+            const int nkb16 = (kend - kbeg + 15) >> 4;
+            const int voa = (int)((long)m * G.lda * 4) + 32 * half, vob = 8 * half * 256 + 8 * l31;
+            int soa = kbeg * 4, sob = kbeg * 256, ccol = kbeg + 8 * half;
+            f32x4 sa[STAGES][2]; f32x2 sb[STAGES][8];
+            auto issue = [&](int u) {
+                sa[u][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa, soa, 0));
+                sa[u][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa + 16, soa, 0));
+#pragma unroll
+                for (int s = 0; s < 8; ++s) sb[u][s] = bld2(rb, vob, sob + s * 256);
+                soa += 64; sob += 16 * 256;
+            };
+#pragma unroll
+            for (int u = 0; u < STAGES; ++u) issue(u);
+            for (int kb = 0; kb < nkb16; kb += STAGES) {
+#pragma unroll
+                for (int u = 0; u < STAGES; ++u) {
+                    if (kb + u >= nkb16) break;
+                    f32x4 x0 = sa[u][0], x1 = sa[u][1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {              // columns past the slice: other splits' / the next row's data
+                        if (ccol + e >= kend) x0[e] = 0.f;
+                        if (ccol + 4 + e >= kend) x1[e] = 0.f;
+                    }
+                    const u32x4 a = pk8(x0, x1);
+                    u32x4 b0, b1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        b0[j] = pk_bf16(sb[u][2 * j].x, sb[u][2 * j + 1].x);
+                        b1[j] = pk_bf16(sb[u][2 * j].y, sb[u][2 * j + 1].y);
+                    }
+                    acc0 = mfma_bf16(a, b0, acc0);
+                    acc1 = mfma_bf16(a, b1, acc1);
+                    ccol += 16;
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
         const int voa = (int)((long)m * G.lda * 4) + 16 * half, vob = 4 * half * 256 + 8 * l31;      // bytes
         int soa = kbeg * 4, sob = kbeg * 256, ccol = kbeg + 4 * half;
         f32x4 sa[STAGES]; f32x2 sb[STAGES][4];
@@ -375,6 +471,7 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
             }
         }
     }
+    }
     float* C = G.slab + (long)split * G.B * 64;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -386,10 +483,13 @@ __device__ __forceinline__ void dh_wave_body(const DhP& G, int wg) {
 // The whole logits backward at the fused shape in ONE launch: workgroups [0, tiles) form dE = dlogits^T . h_last (the
 // dense gradient of the item table, written straight into the gradient buffer: problem Q, 64-row tiles, rows >= M not
 // stored), the rest form the split-K slabs of d(h_last).
+// BFH: both products on the bf16 matrix cores, operands rounded in registers (plans with bf16 storage; the forward logits and the
+// cross-entropy stay fp32)
+template <bool BFH>
 __global__ void __launch_bounds__(256)
 logits_bwd_direct_kernel(const DwProblem Q, int tiles, const DhP H) {
     __shared__ __attribute__((aligned(16))) float red[3][66][64];
-    if ((int)blockIdx.x < tiles) dw_wg_body<4>(Q, 64 * (int)blockIdx.x, 0, 0, red);
-    else dh_wave_body<4>(H, (int)blockIdx.x - tiles);
+    if ((int)blockIdx.x < tiles) dw_wg_body<4, false, BFH>(Q, 64 * (int)blockIdx.x, 0, 0, red);
+    else dh_wave_body<4, BFH>(H, (int)blockIdx.x - tiles);
 }
 
