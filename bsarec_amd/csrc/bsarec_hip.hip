@@ -1291,8 +1291,7 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                     if (sc.nblocks && (!sc.de || !sc.ids32 || !sc.dE)) return -21;
                     ProfScope prof(BSAREC_K_DW1, s);
                     const dim3 dw_grid(8 * cdiv(ns, 8) * (dw_nu - DW.nsmall) + DW.nsmall * DW.small_slabs + sc.nblocks + (tk_here.state ? 1 : 0));
-                    if (p->bf) LAUNCH(dw_direct_kernel<true>, dw_grid, dim3(256), 0, s, DW, tk_here, sc);
-                    else LAUNCH(dw_direct_kernel<false>, dw_grid, dim3(256), 0, s, DW, tk_here, sc);
+                    LAUNCH(dw_direct_kernel, dw_grid, dim3(256), 0, s, DW, tk_here, sc);
                     HIPCHK(hipGetLastError());
                     dw_np = 0; dw_nu = 0; DW.nsmall = 0; DW.small_slabs = 0;
                 }

@@ -336,7 +336,9 @@ __device__ __forceinline__ void dw_wg_body(const DwProblem& Q, int m0, int n0, i
 // too, as the workgroups after the weight-gradient ones: light, latency-bound blocks that fill the slots the big
 // workgroups leave free instead of a launch of their own (11.6 us + a launch boundary at C1).
 struct ScatterP { const float* de; const int* ids32; int T; float* dE; int nblocks; };
-template <bool BFM>
+// (One instantiation for fp32 and bf16-storage plans: with the bf16 loop compiled in, the fp32 path of this kernel measured 0.5 %
+// of the step FASTER than an fp32-only instantiation -- 0.1568 against 0.1575 ms, three A/B pairs on one box; scheduling luck,
+// kept because it is measured.  The logits backward below is the opposite case and has two.)
 __global__ void __launch_bounds__(256)
 dw_direct_kernel(const DwP G, const TickP tk, const ScatterP sc) {
     __shared__ __attribute__((aligned(16))) float red[3][66][64];      // accumulators (64) + bias sums (2) of waves 1..3
@@ -367,7 +369,7 @@ dw_direct_kernel(const DwP G, const TickP tk, const ScatterP sc) {
     const DwUnit u = G.U[ui];
     const DwProblem& Q = G.P[u.prob];
     if (slab >= Q.nslab) return;
-    dw_wg_body<DW_STAGES, BFM>(Q, u.m0, u.n0, slab, red);
+    dw_wg_body<DW_STAGES, true>(Q, u.m0, u.n0, slab, red);
 }
 
 // =============================================================================================
