@@ -349,3 +349,14 @@ def test_p2p_exchange_isa_carries_system_scope(tmp_path):
     a = _kernel_body(dis, "_Z11adam_kernel")
     remote = [ln for ln in a if ln.startswith("global_load_dwordx2") and "sc0 sc1" in ln]
     assert len(remote) >= 2, "adam_kernel does not read the peer arenas with system-scope loads"
+
+
+def test_code_object_has_no_packed_fp32_vector_instructions(tmp_path):
+    """The library is built with -target-feature -packed-fp32-ops (bsarec_amd/build.py): with v_pk_fma_f32 in the FrequencyLayer's
+    DFT the x3_products forward kernel intermittently returned wrong spectra for whole sequences next to its SIMD partners' bf16
+    MFMAs (tools/dbg/x3_case.py).  The back end forms packed fp32 operations from float4 arithmetic on its own, so the
+    guard is on the ISA, not on the source: no packed fp32 arithmetic anywhere in the gfx950 code object."""
+    dis = _disassemble_gfx950(tmp_path)
+    packed = re.findall(r"^\s*(v_pk_(?:fma|mul|add)_f32)\b", dis, re.M)
+    assert not packed, f"{len(packed)} packed fp32 instructions in the code object (build flags lost?)"
+    assert "v_mfma_f32_32x32x16_bf16" in dis and "v_mfma_f32_32x32x2_f32" in dis      # (it is the right code object)
