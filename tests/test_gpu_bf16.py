@@ -199,3 +199,32 @@ def test_bf16_training_follows_fp32_training():
     for lf, lb in zip(res["f32"], res["bf16"]):
         assert abs(lf - lb) <= 0.01 * lf, res
     assert res["bf16"][-1] < res["bf16"][0]
+
+
+@pytest.mark.parametrize("B", [1, 3, 20])
+def test_bf16_tiny_batches_vs_fp32_oracle(B):
+    """One, three and twenty sequences through bf16 storage: the 16-row k-blocks of the bf16 matrix-core loops (weight gradients,
+    logits backward) are then mostly padding -- partial last blocks masked per row, prefetch past the operands answered by the
+    buffer descriptors' range check.  Loss and all gradients vs the fp32 oracle at the bf16 gates."""
+    from oracle import bsarec_oracle as O
+    L, V = 50, 211
+    cfg = O.Config(item_size=V, hidden_size=64, max_seq_length=L, num_hidden_layers=2, num_attention_heads=2,
+                   c=5, alpha=0.7, hidden_dropout_prob=0.2, attention_probs_dropout_prob=0.1)
+    params = O.init_params(cfg, seed=B)
+    rng = np.random.default_rng(100 + B)
+    ids = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        n = L if b == 0 else int(rng.integers(1, L + 1))
+        ids[b, L - n:] = rng.integers(1, V, size=n)
+    ans = rng.integers(1, V, size=B).astype(np.int64)
+    model = build(cfg, params)
+    model.train()
+    model.set_seed(5)
+    loss = model.calculate_loss(torch.from_numpy(ids).cuda(), torch.from_numpy(ans).cuda(), None, None, None)
+    loss.backward()
+    step = int(model._state[1].item())
+    oloss, _, G, _ = O.loss_and_grads(params, cfg, ids, ans, O.DropoutSpec(True, 5, step))
+    ge = grad_errors(model, G)
+    print(f"bf16 B={B}: loss rel {abs(loss.item() - oloss) / abs(oloss):.2e}, worst grad rel-L2 {max(ge.values()):.2e} ({max(ge, key=ge.get)})")
+    assert abs(loss.item() - oloss) <= LOSS_GATE * abs(oloss)
+    assert max(ge.values()) <= GRAD_GATE, {k: v for k, v in ge.items() if v > GRAD_GATE}
