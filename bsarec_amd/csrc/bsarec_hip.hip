@@ -1222,6 +1222,9 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                 // dW2 = dT2^T . act(u): the full fused forward already saved gelu(u) in `u`; elsewhere apply it while loading
                 {p->dT, d, b.u, 4 * d, d, 4 * d, sm.w2, sm.b2, (p->fused && !top_pruned) ? 0 : 1}};
             int tiles = 0;
+            // tile size of the grouped tiled kernel (the direct kernel has its own units): 128 for bf16 products at hidden >= 128 (C3:
+            // 405 -> 337 us per launch); the fp32 form needs 296 registers at 128 x 128 = one wave per SIMD and loses (765 -> 987 us)
+            const int gts = (p->bf_products && d >= 128) ? 128 : 64;
             // Top block: only position L-1 of each sequence carries an upstream gradient (bsarec.py:32), so dq, dO, dU
             // and dT2 are zero on every other row: their four products reduce over the B last positions only
             // (row stride L*ld), exactly; dk and dv still reduce over all tokens.
@@ -1256,9 +1259,9 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                 G.E[i].c_split = (long)sp[i].M * sp[i].N;
                 G.bgrad[i] = compact ? p->slab_dummy : slab_b_ptr(*p, sp[i].boff);
                 G.tile0[i] = tiles;
-                G.tiles_n[i] = cdiv(sp[i].N, 64);
+                G.tiles_n[i] = cdiv(sp[i].N, gts);
                 G.b_gelu[i] = sp[i].gelu;
-                tiles += cdiv(sp[i].M, 64) * G.tiles_n[i];
+                tiles += cdiv(sp[i].M, gts) * G.tiles_n[i];
             }
             G.tile0[6] = tiles; G.nprob = 6; G.act = c.hidden_act;
             if (p->fused && p->direct_dw) {
@@ -1297,9 +1300,15 @@ static int backward_impl(bsarec_plan_t* p, void* stream, const TickP& tick, cons
                 }
             } else {
             ProfScope prof(BSAREC_K_DW1, s);
-            constexpr size_t smem = GemmSmem<64, 64, true, true>::BYTES, smem_bf = GemmSmem<64, 64, true, true, true>::BYTES;
-            if (p->bf_products) LAUNCH(gemm_grouped_tn_kernel<true>, dim3(tiles, ns), dim3(GEMM_THREADS), smem_bf, s, G);
-            else LAUNCH(gemm_grouped_tn_kernel<false>, dim3(tiles, ns), dim3(GEMM_THREADS), smem, s, G);
+#define GROUPED_LAUNCH(BFV, TSV) do { \
+                constexpr size_t sm_ = GemmSmem<TSV, TSV, true, true, BFV>::BYTES; \
+                static bool attr_ = false; \
+                if (!attr_) { if (sm_ > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_grouped_tn_kernel<BFV, TSV>), \
+                                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm_)); attr_ = true; } \
+                LAUNCH((gemm_grouped_tn_kernel<BFV, TSV>), dim3(tiles, ns), dim3(GEMM_THREADS), sm_, s, G); } while (0)
+            if (p->bf_products) { if (gts == 128) GROUPED_LAUNCH(true, 128); else GROUPED_LAUNCH(true, 64); }
+            else GROUPED_LAUNCH(false, 64);
+#undef GROUPED_LAUNCH
             HIPCHK(hipGetLastError());
             }
         }

@@ -169,8 +169,10 @@ struct GroupedTN {
     int act;                        // which hidden_act (0 = gelu)
 };
 
-template <bool BF>          // BF: bf16 products (gemm.h), cfg.storage = 1 outside the fused shape class
-__global__ void __launch_bounds__(GEMM_THREADS)
+// BF: bf16 products (gemm.h), cfg.storage = 1 outside the fused shape class.  TS: tile size -- 128 at hidden >= 128 (the host
+// counts the tiles with the same TS): half the fragment reads and staging writes per MFMA of the 64 x 64 form
+template <bool BF, int TS>
+__global__ void __launch_bounds__(GEMM_THREADS, (BF && TS == 128) ? 2 : 1)
 gemm_grouped_tn_kernel(const GroupedTN G) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int p = 0;
@@ -180,9 +182,9 @@ gemm_grouped_tn_kernel(const GroupedTN G) {
     XformP X;
     X.L = 0; X.Lp = 0; X.drop.thresh = 0; X.drop.scale = 1.f; X.drop.rng = nullptr; X.drop.site = 0; X.act = G.act;
     if (G.b_gelu[p])
-        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_GELU, true, BF>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
+        gemm_body<TS, TS, 2, 2, true, true, XF_NONE, XF_GELU, true, BF>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
     else
-        gemm_body<64, 64, 2, 2, true, true, XF_NONE, XF_NONE, true, BF>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
+        gemm_body<TS, TS, 2, 2, true, true, XF_NONE, XF_NONE, true, BF>(G.P[p], X, G.E[p], G.bgrad[p], bx, by, blockIdx.y, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
