@@ -945,8 +945,19 @@ static int loss_impl(bsarec_plan_t* p, const int64_t* answers, void* stream, boo
     RET(bsarec_logits(p, stream));
     p->loss_kind = 0;
     const bsarec_config_t& c = p->cfg;
-    LAUNCH(ce_rows_kernel, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, c.item_size, p->Vp,
-                       1.0f / (float)c.batch, p->dlogits, p->loss_rows);
+    // up to 4,096 classes: scalar row in registers (C1); up to 24,576: float4 row in registers (C2's Beauty, C4's Yelp catalogue);
+    // beyond: streamed in three passes (C5: 40 MB rows)
+    const int V = c.item_size;
+    const float inv_b = 1.0f / (float)c.batch;
+#define CE_VEC(N4) LAUNCH(ce_rows_vec_kernel<N4>, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, V, p->Vp, inv_b, p->dlogits, p->loss_rows)
+    if (V <= CE_MAX_PER_THREAD * ROW_THREADS || V > 24 * 4 * ROW_THREADS)
+        LAUNCH(ce_rows_kernel, dim3(c.batch), dim3(ROW_THREADS), 0, s, p->logits, answers, V, p->Vp, inv_b, p->dlogits, p->loss_rows);
+    else if (V <= 8 * 4 * ROW_THREADS) CE_VEC(8);
+    else if (V <= 12 * 4 * ROW_THREADS) CE_VEC(12);
+    else if (V <= 16 * 4 * ROW_THREADS) CE_VEC(16);
+    else if (V <= 20 * 4 * ROW_THREADS) CE_VEC(20);
+    else CE_VEC(24);
+#undef CE_VEC
     HIPCHK(hipGetLastError());
     if (with_mean) LAUNCH(loss_mean_kernel, dim3(1), dim3(ROW_THREADS), 0, s, p->loss_rows, c.batch, p->loss);
     return (int)hipGetLastError();
