@@ -932,6 +932,18 @@ extern "C" int bsarec_logits(bsarec_plan_t* p, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const bsarec_config_t& c = p->cfg;
     const int d = c.hidden, L = c.seq_len;
+    // hidden = 64 and a small problem: straight from global memory into the MFMA operands (dw_direct.h).  Measured on one box:
+    // C1 (B = 256, V = 3,417) 0.1569 -> 0.1551 ms/step; at B = 256 x V = 12,102 and 1,024 x 20,034 the direct form LOSES (every
+    // 32-row block re-reads the whole table, 4-byte stores: 0.134 -> 0.140 and 0.661 -> 0.687 ms) -- those keep the tiled GEMM
+    if (p->fused && d == 64 && p->Vp <= 4096 && c.batch <= 512 && !g_dry) {
+        LogitsP G;
+        G.H = p->X[c.layers] + (long)(L - 1) * d; G.ldh = (long)L * d; G.E = p->P.item_emb; G.C = p->logits;
+        G.B = c.batch; G.V = c.item_size; G.Vp = p->Vp;
+        const long units = (long)cdiv(c.batch, 32) * cdiv(p->Vp, 32);
+        ProfScope prof(BSAREC_K_LOGITS, s);
+        hipLaunchKernelGGL(logits_direct_kernel, dim3((unsigned)cdiv(units, 4)), dim3(256), 0, s, G);
+        return (int)hipGetLastError();
+    }
     GemmP g = gemm_defaults(c.batch, p->Vp, d);
     g.Nb = c.item_size; g.lda = (long)L * d; g.ldb = d;
     g.A[0] = p->X[c.layers] + (long)(L - 1) * d; g.B[0] = p->P.item_emb;

@@ -495,3 +495,44 @@ logits_bwd_direct_kernel(const DwProblem Q, int tiles, const DhP H) {
     else dh_wave_body<4, BFH>(H, (int)blockIdx.x - tiles);
 }
 
+// =============================================================================================
+// logits[b][v] = h_last[b] . E[v] at hidden = 64, the same direct way (no LDS, no barriers): a wave owns 32 batch rows x 32
+// items; lane (l31, half) loads the k half [32 half, 32 half + 32) of ITS batch row and of ITS item row as 8 + 8 16-byte
+// loads (both operands are k-contiguous; the k order is any bijection as long as A and B share it) and chains 32 MFMAs.  The
+// tiled GEMM this replaces on the fused path staged a K = 64 product through LDS twice (operands, then the C tile) for a
+// 6.5 us launch at C1, 45 us at C4's 1,024 x 20,034.  Pad columns V .. Vp are written as 0 (BSAREC_BUF_LOGITS contract).
+// =============================================================================================
+struct LogitsP { const float* H; long ldh; const float* E; float* C; int B, V, Vp; };
+__global__ void __launch_bounds__(256)
+logits_direct_kernel(const LogitsP G) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    const int ntile = (G.Vp + 31) >> 5, mtiles = (G.B + 31) >> 5;
+    const int unit = blockIdx.x * 4 + wv;                 // item tile fastest: the 4 waves of a workgroup share one batch-row block
+    const int nt = unit % ntile, mt = unit / ntile;
+    if (mt >= mtiles) return;
+    const int m = min(32 * mt + l31, G.B - 1);             // rows / items past the end re-read the last one; never stored
+    const int v = min(32 * nt + l31, G.V - 1);
+    const float* ap = G.H + (long)m * G.ldh + 32 * half;
+    const float* bp = G.E + (long)v * 64 + 32 * half;
+    f32x4 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = gld4(ap + 4 * i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = gld4(bp + 4 * i);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[i][j], acc, 0, 0, 0);
+    const int col = 32 * nt + l31;
+    if (col >= G.Vp) return;
+    const bool real = col < G.V;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * mt + rho(r) + 4 * half;
+        if (row < G.B) gst(G.C + (long)row * G.Vp + col, real ? acc[r] : 0.f);
+    }
+}
